@@ -1,0 +1,339 @@
+"""Generate the golden vectors in tests/golden/*.pt by IMPORTING THE REFERENCE itself.
+
+Runs only in the build container (the reference lives at /root/reference and never travels);
+the fixtures it writes are data: inputs are regenerated from seeds by tests/golden/common.py,
+expected outputs come from the unmodified reference classes/functions.
+
+    python tests/golden/make_golden.py            # all small fixtures (~1 min)
+    python tests/golden/make_golden.py --full     # also the B=64, L=512 record (~2 min)
+
+torch_geometric (an unrelated import of the reference's dataset module) is absent here, so an
+empty stand-in module is registered before the import; no reference code is changed.
+The reference draws its noise with torch.rand / rand / randn on the CPU generator
+(wgan_gp.py:58,228,291); those three names are patched to pop pre-drawn tensors so the same
+noise can be replayed by the oracle and by the HIP path.
+"""
+from __future__ import annotations
+
+import argparse
+import contextlib
+import os
+import sys
+import types
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import common  # noqa: E402
+
+
+def import_reference():
+    for name in ("torch_geometric", "torch_geometric.data", "torch_geometric.utils"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["torch_geometric.data"].Dataset = object
+    sys.modules["torch_geometric.data"].Data = object
+    sys.modules["torch_geometric.utils"].dropout_edge = lambda *a, **k: None
+    sys.path.insert(0, "/root/reference")
+    import wgan_gp as ref
+    return ref
+
+
+class Queue:
+    def __init__(self):
+        self.items = []
+
+    def push(self, *ts):
+        self.items.extend(ts)
+
+    def pop(self, *shape_args, **kw):
+        t = self.items.pop(0)
+        return t.clone()
+
+
+@contextlib.contextmanager
+def injected(ref, q_rand_torch: Queue, q_rand: Queue, q_randn: Queue):
+    """torch.rand -> Gumbel U (wgan_gp.py:58); ref.rand -> alpha (:228); ref.randn -> z (:291)."""
+    old = (torch.rand, ref.rand, ref.randn)
+    torch.rand = q_rand_torch.pop
+    ref.rand = q_rand.pop
+    ref.randn = q_randn.pop
+    try:
+        yield
+    finally:
+        torch.rand, ref.rand, ref.randn = old
+
+
+def save(name, obj):
+    path = os.path.join(HERE, name)
+    torch.save(obj, path)
+    print(f"wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def load_critic(ref, p, vocab=175, drop=0.0):
+    D = ref.Discriminator(vocab, 50, 2, 2, drop_rate=drop)
+    D.load_state_dict(p)
+    return D
+
+
+def load_generator(ref, p, vocab, seq_len):
+    G = ref.Generator(vocab, 2)
+    if seq_len != G.seq_len:   # only reference code paths are used for the forward
+        G.seq_len = seq_len
+        G.model[-1] = torch.nn.Linear(512, vocab * seq_len)
+    sd = dict(p)
+    sd.update(common.bn_buffers())
+    G.load_state_dict(sd)
+    return G
+
+
+def g1_sampler(ref):
+    g = common.gen(101)
+    logits = torch.randn((4, 8, 175), generator=g) * 2
+    U = torch.rand((4, 8, 175), generator=g)
+    dy = torch.randn((4, 8, 175), generator=g)
+    out = {}
+    sm = ref.CustomSoftmax()
+    for tau in (0.5, 1.0, 5.0):
+        for hard in (False, True):
+            lg = logits.clone().requires_grad_(True)
+            q = Queue(); q.push(U)
+            with injected(ref, q, Queue(), Queue()):
+                y = sm(lg, tau, hard)
+            (dl,) = torch.autograd.grad(y, lg, dy)
+            out[f"y_tau{tau}_hard{int(hard)}"] = y.detach()
+            out[f"dlogits_tau{tau}_hard{int(hard)}"] = dl
+    out["relaxed_tau0.7"] = ref.CustomSoftmax("relaxed_bernoulli")(logits, 0.7, False)
+    out["plain"] = ref.CustomSoftmax("softmax")(logits, 0.7, False)
+    out["anneal"] = torch.tensor([ref.CustomSoftmax.anneal_tau_(5.0, 0.5, e, 100, 10) for e in (0, 7, 10, 50)])
+    save("g1_sampler.pt", out)
+
+
+def g2_generator(ref):
+    out = {}
+    for seq_len in (8, 120):
+        p = common.generator_params(202, 175, seq_len)
+        G = load_generator(ref, p, 175, seq_len)
+        G.train()
+        nz = common.noise(203, 6, seq_len)
+        labels = torch.tensor([0, 1, 1, 0, 1, 0])
+        q = Queue(); q.push(nz["U"])
+        with injected(ref, q, Queue(), Queue()):
+            y = G(nz["z"], labels, 0.5, False)
+        dy = torch.randn(y.shape, generator=common.gen(204))
+        names = [n for n, _ in G.named_parameters()]
+        grads = torch.autograd.grad(y, list(G.parameters()), dy)
+        tag = f"T{seq_len}"
+        out[f"{tag}.y"] = y.detach() if seq_len == 8 else y.detach()[:, :4].clone()
+        for n, gr in zip(names, grads):
+            if n == "model.8.weight" and seq_len == 120:
+                out[f"{tag}.grad_norm.{n}"] = gr.norm()
+                out[f"{tag}.grad_head.{n}"] = gr[:64].clone()
+            else:
+                out[f"{tag}.grad.{n}"] = gr
+        for b in ("model.3.running_mean", "model.3.running_var", "model.6.running_mean", "model.6.running_var"):
+            out[f"{tag}.{b}"] = G.state_dict()[b].clone()
+        # eval-mode forward (generate_fake_data.py:61-66) after the one training call above
+        G.eval()
+        q = Queue(); q.push(nz["U2"])
+        with injected(ref, q, Queue(), Queue()), torch.no_grad():
+            tok = G(nz["z"], labels, 0.5, True).argmax(-1)
+        out[f"{tag}.eval_tokens"] = tok
+    save("g2_generator.pt", out)
+
+
+def g3_critic(ref):
+    out = {}
+    p = common.critic_params(301, scale=2.0)
+    D = load_critic(ref, p)
+    D.train()
+    g = common.gen(302)
+    x = torch.softmax(torch.randn((4, 16, 175), generator=g) * 3, -1)
+    dout = torch.randn((4, 3), generator=g)
+    lengths = torch.tensor([16, 11, 7, 3])
+    from torch.nn.utils.rnn import pack_padded_sequence
+    for tag, use_len in (("dense", False), ("packed", True)):
+        xin = x.clone().requires_grad_(True)
+        inp = pack_padded_sequence(xin, lengths, batch_first=True, enforce_sorted=False) if use_len else xin
+        o = D(inp)
+        names = [n for n, _ in D.named_parameters()]
+        grads = torch.autograd.grad(o, [xin] + list(D.parameters()), dout)
+        out[f"{tag}.out"] = o.detach()
+        out[f"{tag}.dx"] = grads[0]
+        for n, gr in zip(names, grads[1:]):
+            out[f"{tag}.grad.{n}"] = gr
+    save("g3_critic.pt", out)
+
+
+def g4_gp(ref):
+    out = {}
+    for scale, tag in ((1.0, "s1"), (3.0, "s3")):
+        p = common.critic_params(401, scale=scale)
+        D = load_critic(ref, p)
+        D.train()
+        tokens, labels, lengths = common.batch(402, 5, 12, lengths=[12, 12, 9, 4, 1])
+        real = torch.nn.functional.one_hot(tokens, 175).float()
+        g = common.gen(403)
+        for Tf in (7, 12, 15):
+            fake = torch.softmax(torch.randn((5, Tf, 175), generator=g) * 2, -1)
+            alpha = torch.rand((5, 1, 1), generator=g)
+            q = Queue(); q.push(alpha)
+            with injected(ref, Queue(), q, Queue()):
+                gp = ref.compute_gradient_penalty(D, real, fake, labels, lengths)
+            names = [n for n, _ in D.named_parameters()]
+            grads = torch.autograd.grad(10.0 * gp, list(D.parameters()), allow_unused=True)
+            k = f"{tag}.Tf{Tf}"
+            out[f"{k}.fake"] = fake
+            out[f"{k}.alpha"] = alpha
+            out[f"{k}.gp"] = gp.detach()
+            for n, gr in zip(names, grads):
+                if gr is not None:
+                    out[f"{k}.grad.{n}"] = gr
+    save("g4_gp.pt", out)
+
+
+def g5_ce(ref):
+    g = common.gen(501)
+    logits = torch.randn((9, 2), generator=g).requires_grad_(True)
+    labels = torch.tensor([0, 1, 1, 0, 0, 1, 1, 1, 0])
+    crit = torch.nn.CrossEntropyLoss(torch.tensor([1.0, 2.0]))
+    loss = crit(torch.softmax(logits, -1), labels)   # wgan_gp.py:268,299,310
+    (dl,) = torch.autograd.grad(loss, logits)
+    save("g5_ce.pt", {"logits": logits.detach(), "labels": labels, "loss": loss.detach(), "dlogits": dl})
+
+
+def g6_adam(ref):
+    g = common.gen(601)
+    w = torch.randn((7, 5), generator=g).requires_grad_(True)
+    w2 = torch.randn((3,), generator=g).requires_grad_(True)
+    opt = torch.optim.Adam([w, w2], lr=2e-4, betas=(0.5, 0.999))
+    out = {"w0": w.detach().clone(), "w20": w2.detach().clone()}
+    for s in range(3):
+        opt.zero_grad()
+        gw = torch.randn((7, 5), generator=g) * (10.0 ** (s - 1))
+        w.grad = gw.clone()
+        out[f"gw{s}"] = gw
+        if s != 1:                       # step 1: w2 has no grad -> Adam skips it
+            gw2 = torch.randn((3,), generator=g)
+            w2.grad = gw2.clone()
+            out[f"gw2{s}"] = gw2
+        else:
+            w2.grad = None
+        opt.step()
+        out[f"w{s + 1}"] = w.detach().clone()
+        out[f"w2{s + 1}"] = w2.detach().clone()
+    save("g6_adam.pt", out)
+
+
+class ListLoader(list):
+    pass
+
+
+def run_reference_steps(ref, pg, pd, batches, noises, vocab, gen_seq_len, opt_ns):
+    """Drive the reference's own train_wgan (wgan_gp.py:261-348) over the given batches."""
+    G = load_generator(ref, pg, vocab, gen_seq_len)
+    D = load_critic(ref, pd, vocab, drop=0.0)
+    oG = torch.optim.Adam(G.parameters(), lr=opt_ns.lr, betas=(opt_ns.b1, opt_ns.b2))
+    oD = torch.optim.Adam(D.parameters(), lr=opt_ns.lr, betas=(opt_ns.b1, opt_ns.b2))
+    snaps = {"D": [], "G": []}
+
+    def snap(tag, mod):
+        def hook(opt, args, kwargs):
+            snaps[tag].append({n: (None if q.grad is None else q.grad.detach().clone())
+                               for n, q in mod.named_parameters()})
+        return hook
+    oD.register_step_pre_hook(snap("D", D))
+    oG.register_step_pre_hook(snap("G", G))
+    qU, qA, qZ = Queue(), Queue(), Queue()
+    for i, nz in enumerate(noises):
+        qZ.push(nz["z"]); qU.push(nz["U"]); qA.push(nz["alpha"])
+        if i % opt_ns.n_critic == 0:
+            qU.push(nz["U2"])
+    import io
+    buf = io.StringIO()
+    with injected(ref, qU, qA, qZ), contextlib.redirect_stdout(buf), contextlib.redirect_stderr(io.StringIO()):
+        ref.train_wgan(G, D, oG, oD, ListLoader(batches), ListLoader([]), opt_ns, torch.device("cpu"))
+    return G, D, buf.getvalue(), snaps
+
+
+def parse_losses(text):
+    import re
+    return [(float(a), float(b)) for a, b in re.findall(r"\[D loss: ([-\d.eE+naninf]+)\] \[G loss: ([-\d.eE+naninf]+)\]", text)]
+
+
+def g7_full_step(ref):
+    ns = argparse.Namespace(vocab_size=175, epochs=1, batch_size=8, lr=2e-4, b1=0.5, b2=0.999, latent_dim=100,
+                            seq_len=32, n_critic=5, clip_value=0.01, lambda_gp=10.0, hard=False, tau=0.5)
+    out = {}
+    for Tf in (4, 32):
+        pg = common.generator_params(701, 175, Tf)
+        pd = common.critic_params(702, scale=1.5)
+        batches = [common.batch(710 + i, 8, 32, min_len=3) for i in range(6)]
+        noises = [common.noise(720 + i, 8, Tf) for i in range(6)]
+        # 6 batches: generator updates at i = 0 and i = 5, so the second update sees 5 critic steps
+        G, D, text, snaps = run_reference_steps(ref, pg, pd, batches, noises, 175, Tf, ns)
+        k = f"Tf{Tf}"
+        out[f"{k}.printed_losses"] = torch.tensor(parse_losses(text), dtype=torch.float64)
+        for it in (0, 5):
+            for n, v in snaps["D"][it].items():
+                out[f"{k}.D.grad{it}.{n}"] = v
+        for n, v in D.state_dict().items():
+            out[f"{k}.D.{n}"] = v.clone()
+        for n, v in G.state_dict().items():
+            if n == "model.8.weight" and Tf == 32:
+                out[f"{k}.G.delta_norm.{n}"] = (v - pg[n]).norm()
+                out[f"{k}.G.head.{n}"] = v[:32].clone()
+            else:
+                out[f"{k}.G.{n}"] = v.clone()
+    save("g7_full_step.pt", out)
+
+
+def g8_full_size(ref):
+    """One critic iteration + the generator update at the north-star shape: B=64, L=512, V=175,
+    generator seq_len 512, fixed lengths and ADFA-shaped lengths.  Scalars and norms only."""
+    import time
+    ns = argparse.Namespace(vocab_size=175, epochs=1, batch_size=64, lr=2e-4, b1=0.5, b2=0.999, latent_dim=100,
+                            seq_len=512, n_critic=5, clip_value=0.01, lambda_gp=10.0, hard=False, tau=0.5)
+    out = {}
+    for tag, lengths in (("fixed", [512] * 64), ("adfa", common.adfa_lengths(805, 64).tolist())):
+        pg = common.generator_params(801, 175, 512)
+        pd = common.critic_params(802)
+        batches = [common.batch(810, 64, 512, lengths=lengths)]
+        noises = [common.noise(820, 64, 512)]
+        t0 = time.time()
+        G, D, text, snaps = run_reference_steps(ref, pg, pd, batches, noises, 175, 512, ns)
+        out[f"{tag}.seconds"] = torch.tensor(time.time() - t0)
+        out[f"{tag}.printed_losses"] = torch.tensor(parse_losses(text), dtype=torch.float64)
+        for n, v in snaps["D"][0].items():
+            out[f"{tag}.D.grad.{n}"] = v
+        for n, v in snaps["G"][0].items():
+            if v.numel() > 200000:
+                out[f"{tag}.G.grad_norm.{n}"] = v.norm()
+                out[f"{tag}.G.grad_head.{n}"] = v.reshape(-1)[:4096].clone()
+            else:
+                out[f"{tag}.G.grad.{n}"] = v
+        for n, v in G.state_dict().items():
+            if "running" in n:
+                out[f"{tag}.G.{n}"] = v.clone()
+        print(tag, "reference seconds", float(out[f"{tag}.seconds"]), out[f"{tag}.printed_losses"])
+    save("g8_full_size.pt", out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--full", action="store_true")
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    torch.manual_seed(0)
+    ref = import_reference()
+    todo = [g1_sampler, g2_generator, g3_critic, g4_gp, g5_ce, g6_adam, g7_full_step]
+    if a.full:
+        todo.append(g8_full_size)
+    for fn in todo:
+        if a.only and a.only not in fn.__name__:
+            continue
+        fn(ref)
+
+
+if __name__ == "__main__":
+    main()
