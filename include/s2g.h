@@ -1,0 +1,155 @@
+/* libs2g -- C ABI of the MI355X (gfx950) kernels behind the WGAN-GP training step of
+ * sequence-to-graph-gan.
+ *
+ * The reference is pure Python/PyTorch and has no FFI; the boundary a maintainer sees is the
+ * Python module surface of wgan_gp.py (Generator, Discriminator, CustomSoftmax,
+ * compute_gradient_penalty, train_wgan).  Each entry point below replaces the PyTorch
+ * operation(s) cited next to it and is what a ctypes binding in wgan_gp.py calls.
+ *
+ * Conventions: every function enqueues work on `stream` (a hipStream_t passed as void*) and
+ * returns immediately; it never allocates, frees or synchronises.  Return value 0 = enqueued,
+ * negative = rejected (bad argument: -1, launch failure: -2; nothing was enqueued for -1).
+ * All pointers are device pointers to fp32 data unless stated; matrices are row-major.
+ *
+ * Internal gate order.  torch.nn.LSTM stores the 4H gate rows as blocks i|f|g|o (row q*H+u).
+ * Every 200-wide buffer of this library (projections, saved gates, gate gradients) uses
+ * row j' = 4*u + q instead, so the four gates of one hidden unit sit in one quad of lanes.
+ * s2g_pack_critic builds the permuted copies of W_ih0; weight gradients are returned in
+ * torch order by s2g_reduce_slabs(permute_rows = 1).
+ */
+#ifndef S2G_H
+#define S2G_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define S2G_HIDDEN 50
+#define S2G_GATES 200
+#define S2G_MASK_WIDTH 52
+
+int s2g_version(void);
+
+/* One sequence of a critic batch; xproj_t = ca * WT0[token_t] + cp * P[p_off + t] (t < p_len) + b0.
+ * All sequences of a launch own rows [ws_row, ws_row + len) of every workspace buffer. */
+typedef struct S2GSeq {
+  int len, tok_off, p_off, p_len;
+  float ca, cp;
+  int mask_off, ws_row;
+} S2GSeq;
+
+/* ---- sampler: CustomSoftmax.forward / gumbel_softmax / relaxed_bernoulli (wgan_gp.py:36-104).
+ * mode 0 gumbel (needs U, the torch.rand draw of :58), 1 softmax(logits/tau), 2 softmax(logits).
+ * hard != 0: y_out = one-hot(argmax), y_soft (may be NULL when hard == 0) keeps the soft sample
+ * for the straight-through backward (:80-84).  bias (optional) is added to the logits first,
+ * indexed [(row % bias_rows) * V + j] (the last generator Linear's bias, wgan_gp.py:159). */
+int s2g_gumbel_softmax_fwd(const float* logits, const float* U, const float* bias, int bias_rows,
+                           float* y_out, float* y_soft, long rows, int V, float tau, int mode, int hard,
+                           void* stream);
+/* autograd of the above: dlogits = scale * y * (dy - <dy, y>), scale = 1/tau (modes 0,1) or 1. */
+int s2g_gumbel_softmax_bwd(const float* y_soft, const float* dy, float* dlogits, long rows, int V,
+                           float scale, void* stream);
+/* tokens = y.argmax(-1) as int64 (generate_fake_data.py:66). */
+int s2g_argmax_rows(const float* y, long long* tokens, long rows, int V, void* stream);
+
+/* ---- exact-fp32 MFMA GEMM: nn.Linear / the W_ih product of nn.LSTM / every weight gradient.
+ * C[m][n] = act(alpha * sum_k A[m*sam + ka*sak] * B[kb*sbk + n*sbn] + bias[n]) (+ C if accumulate);
+ * segT > 0 maps k = b*segT + t to ka = b*a_seg + t, kb = b*b_seg + t (- 1 and zero at t == 0 when
+ * shift); nsplit > 1 writes K-slices to C + z*slab.  act 1 = LeakyReLU(0.2) (wgan_gp.py:151). */
+typedef struct S2GGemm {
+  const float* A; long sam, sak;
+  const float* B; long sbk, sbn;
+  float* C; long ldc; long slab;
+  const float* bias;
+  int M, N, K, kchunk, segT, a_seg, b_seg, shift, accumulate, act;
+  float alpha;
+} S2GGemm;
+int s2g_gemm_f32(const S2GGemm* args, int nsplit, void* stream);
+int s2g_reduce_slabs(const float* slabs, long slab, int nslab, int rows, int cols, float* out,
+                     int permute_rows, int accumulate, float scale, void* stream);
+/* part[chunk][c] = sum over a chunk of rows of X[r*ld + c]; nchunk = ceil(rows / rows_per_chunk). */
+int s2g_colsum(const float* X, long ld, long rows, int cols, float* part, long rows_per_chunk, void* stream);
+
+/* ---- critic LSTM sweeps: nn.LSTM(175, 50, 2, batch_first, dropout) inside
+ * Discriminator.forward (wgan_gp.py:189, 217-220) and its autograd.
+ * Buffers indexed by workspace row: gates*, delta*, adot*, abar*, cell*, celld* are [rows, 200];
+ * adj* is [rows, 100]; mask is [rows, 52] (dropout multiplier of layer-0 outputs, NULL = none);
+ * hT/dhT/hdotT are [nseq, 50].  whh0/wih1/whh1 are the torch parameters [200, 50]. */
+int s2g_lstm2_fwd(const S2GSeq* seqs, int nseq, int max_len, const int* tokens, const float* WT0,
+                  const float* P, const float* mask, const float* b0, const float* b1, const float* whh0,
+                  const float* wih1, const float* whh1, float* gates0, float* cell0, float* gates1,
+                  float* cell1, float* hT, void* stream);
+/* reverse sweep for d(loss)/d(h1_final) = dhT: what d_loss.backward() (wgan_gp.py:317) and
+ * autograd.grad(..., inputs=interpolates) (:247-254) run through the LSTM.  adj0/adj1 may be NULL;
+ * otherwise sequences n >= adj_seq0 store (dh_t, dc_t) at adj row (ws_row + t - adj_row0).
+ * rows_per_seq: workspace rows reserved per sequence (rows >= len are zero-filled in delta*). */
+int s2g_lstm2_bwd(const S2GSeq* seqs, int nseq, int rows_per_seq, const float* mask, const float* whh0,
+                  const float* wih1, const float* whh1, const float* gates0, const float* cell0,
+                  const float* gates1, const float* cell1, const float* dhT, float* delta0, float* delta1,
+                  float* adj0, float* adj1, int adj_seq0, int adj_row0, void* stream);
+/* tangent (forward-mode) sweep along an input direction whose projection is Xdot [rows, 200];
+ * with s2g_lstm2_bwd2 it replaces the double backward that create_graph=True makes autograd
+ * run for the gradient penalty (wgan_gp.py:251, 256, 317). */
+int s2g_lstm2_tangent(const S2GSeq* seqs, int nseq, const float* Xdot, const float* mask, const float* whh0,
+                      const float* wih1, const float* whh1, const float* gates0, const float* cell0,
+                      const float* gates1, const float* cell1, float* adot0, float* celld0, float* adot1,
+                      float* celld1, float* hdotT, void* stream);
+int s2g_lstm2_bwd2(const S2GSeq* seqs, int nseq, int rows_per_seq, const float* mask, const float* whh0,
+                   const float* wih1, const float* whh1, const float* gates0, const float* cell0,
+                   const float* gates1, const float* cell1, const float* adot0, const float* celld0,
+                   const float* adot1, const float* celld1, const float* adj0, const float* adj1,
+                   float* abar0, float* abar1, void* stream);
+
+/* permuted copies of lstm.weight_ih_l0 and the summed biases (Discriminator parameters,
+ * wgan_gp.py:189): WT0 [V,200], W0p [200,V], b0/b1 [200]. */
+int s2g_pack_critic(const float* wih0, const float* bih0, const float* bhh0, const float* bih1,
+                    const float* bhh1, float* WT0, float* W0p, float* b0, float* b1, int V, void* stream);
+/* sequence descriptors of the fused critic batch [real B | fake B | interp B | interp B with
+ * group-relative rows] (wgan_gp.py:297-307); seqs has room for 4B entries */
+int s2g_critic_batch_desc(const int* lengths, const float* alpha, int B, int T, int Tf, int use_mask,
+                          S2GSeq* seqs, void* stream);
+
+/* ---- critic head and losses: self.fc (wgan_gp.py:222) and lines 298-315 / 333-340 */
+int s2g_head_fwd(const float* hT, const float* W, const float* b, float* out, int N, int J, void* stream);
+int s2g_head_bwd_dh(const float* dout, const float* W, float* dhT, int N, int J, void* stream);
+int s2g_head_bwd_w(const float* dout, const float* hT, float* dW, float* db, int N, int J, int accumulate,
+                   void* stream);
+int s2g_critic_loss(const float* out, const long long* labels, int B, float inv_n, float inv_wsum, float w0,
+                    float w1, float* dout, float* losses, void* stream);
+int s2g_generator_loss(const float* out, const long long* labels, int B, float inv_n, float inv_wsum,
+                       float w0, float w1, float* dout, float* losses, void* stream);
+
+/* ---- gradient penalty pieces: compute_gradient_penalty (wgan_gp.py:225-257) */
+int s2g_one_hot(const int* tokens, const int* lengths, int T, float* x, long rows, int V, void* stream);
+int s2g_gp_interp(const int* tokens, const int* lengths, const float* fake, const float* alpha, int B, int T,
+                  int Tf, int V, float* xhat, void* stream);
+/* per sample b: norms[b] = |g_b|, pen[b] = (|g_b| - 1)^2 and, when scale_in_place,
+ * g_b <- upstream * 2 (|g_b| - 1) / (n_batch |g_b|) * g_b */
+int s2g_gp_norm_penalty(float* g, int B, long per_sample, float upstream, float n_batch, float* pen,
+                        float* norms, int scale_in_place, void* stream);
+int s2g_gp_scale(const float* g, const float* norms, const float* upstream, float n_batch, long per_sample,
+                 float* v, int B, void* stream);
+
+/* ---- generator glue: Generator.forward (wgan_gp.py:165-171), BatchNorm1d(n, eps=0.8) + LeakyReLU */
+int s2g_embed_mul(const float* z, const long long* labels, const float* emb, float* out, int B, int D,
+                  void* stream);
+int s2g_embed_mul_bwd(const float* z, const long long* labels, const float* dout, float* demb, int B, int D,
+                      int n_classes, void* stream);
+int s2g_lrelu_bwd(const float* y, float* dy, long n, void* stream);
+int s2g_bn_stats(const float* x, float* stats, int B, int F, void* stream);
+int s2g_bn_lrelu_apply(const float* x, const float* stats, float n_global, const float* gamma,
+                       const float* beta, float* run_mean, float* run_var, float eps, float momentum,
+                       int update_running, float* y, float* xhat, float* invstd, int B, int F, void* stream);
+int s2g_bn_lrelu_bwd_stats(const float* y, float* dy, const float* xhat, float* sums, int B, int F,
+                           void* stream);
+int s2g_bn_bwd_apply(const float* dyh, const float* xhat, const float* sums, float n_global,
+                     const float* gamma, const float* invstd, float* dx, int B, int F, void* stream);
+
+/* ---- optimiser: torch.optim.Adam(lr, betas) as built at wgan_gp.py:405-406; `step` counts from 1;
+ * the gradient is multiplied by gscale first (1/world_size after a SUM all-reduce). */
+int s2g_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+             int step, float gscale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,398 @@
+// HBM-bound element-wise / small-reduction kernels of the WGAN-GP step: generator glue
+// (label-embedding product, BatchNorm(batch stats, eps=0.8)+LeakyReLU(0.2), wgan_gp.py:147-171),
+// fused Adam (torch.optim.Adam as constructed at wgan_gp.py:405-406), critic weight packing,
+// one-hot encoding of real tokens (wgan_gp.py:277), the critic head + losses
+// (wgan_gp.py:220-222, 298-315, 333-340) and the gradient-penalty pieces (wgan_gp.py:228-256).
+#include "s2g_common.h"
+
+// ------------------------------------------------------------------ generator glue
+// out[b][k] = z[b][k] * emb[labels[b]][k]                                   (wgan_gp.py:166-167)
+extern "C" __global__ void s2g_k_embed_mul(const float* __restrict__ z, const long long* __restrict__ labels,
+                                           const float* __restrict__ emb, float* __restrict__ out, int B, int D) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * D) return;
+  int b = i / D, k = i % D;
+  out[i] = z[i] * emb[labels[b] * D + k];
+}
+// demb[c][k] = sum_{b: labels[b]==c} z[b][k] * dout[b][k]   (one thread per (c,k); B is small)
+extern "C" __global__ void s2g_k_embed_mul_bwd(const float* __restrict__ z, const long long* __restrict__ labels,
+                                               const float* __restrict__ dout, float* __restrict__ demb, int B,
+                                               int D, int n_classes) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_classes * D) return;
+  int c = i / D, k = i % D;
+  float s = 0.0f;
+  for (int b = 0; b < B; ++b)
+    if (labels[b] == c) s += z[b * D + k] * dout[b * D + k];
+  demb[i] = s;
+}
+
+// y = x > 0 ? x : 0.2 x  applied in place is fused into the GEMM epilogue; its backward:
+extern "C" __global__ void s2g_k_lrelu_bwd(const float* __restrict__ y, float* __restrict__ dy, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dy[i] = y[i] > 0.0f ? dy[i] : 0.2f * dy[i];
+}
+
+// BatchNorm1d over the batch axis, split in two so data-parallel ranks can all-reduce the
+// per-feature sums in between (SyncBN):   stats[0][f] = sum_b x, stats[1][f] = sum_b x^2.
+extern "C" __global__ void s2g_k_bn_stats(const float* __restrict__ x, float* __restrict__ stats, int B, int F) {
+  int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  float s = 0.0f, q = 0.0f;
+  for (int b = 0; b < B; ++b) { float v = x[(long)b * F + f]; s += v; q = fmaf(v, v, q); }
+  stats[f] = s; stats[F + f] = q;
+}
+// training: mean/var from the (global) sums over n_global rows; updates the running stats with
+// momentum and the unbiased variance exactly once (update_running != 0).  eval: stats == nullptr,
+// normalise with the running stats.  Saves xhat and invstd for the backward.  y = lrelu(bn(x)).
+extern "C" __global__ void s2g_k_bn_lrelu_apply(const float* __restrict__ x, const float* __restrict__ stats,
+                                                float n_global, const float* __restrict__ gamma,
+                                                const float* __restrict__ beta, float* __restrict__ run_mean,
+                                                float* __restrict__ run_var, float eps, float momentum,
+                                                int update_running, float* __restrict__ y,
+                                                float* __restrict__ xhat, float* __restrict__ invstd_out, int B,
+                                                int F) {
+  int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  float mean, var;
+  if (stats) {
+    mean = stats[f] / n_global;
+    var = fmaxf(stats[F + f] / n_global - mean * mean, 0.0f);
+    if (update_running) {
+      float unb = n_global > 1.0f ? var * n_global / (n_global - 1.0f) : var;
+      run_mean[f] = (1.0f - momentum) * run_mean[f] + momentum * mean;
+      run_var[f] = (1.0f - momentum) * run_var[f] + momentum * unb;
+    }
+  } else {
+    mean = run_mean[f]; var = run_var[f];
+  }
+  float inv = 1.0f / sqrtf(var + eps);
+  if (invstd_out) invstd_out[f] = inv;
+  float ga = gamma[f], be = beta[f];
+  for (int b = 0; b < B; ++b) {
+    long i = (long)b * F + f;
+    float xh = (x[i] - mean) * inv;
+    if (xhat) xhat[i] = xh;
+    float v = fmaf(xh, ga, be);
+    y[i] = v > 0.0f ? v : 0.2f * v;
+  }
+}
+// backward, part 1: dyh = dy * lrelu'(y) (written back to dy); sums[0][f] = sum dyh (= dbeta),
+// sums[1][f] = sum dyh * xhat (= dgamma)
+extern "C" __global__ void s2g_k_bn_lrelu_bwd_stats(const float* __restrict__ y, float* __restrict__ dy,
+                                                    const float* __restrict__ xhat, float* __restrict__ sums,
+                                                    int B, int F) {
+  int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  float s = 0.0f, q = 0.0f;
+  for (int b = 0; b < B; ++b) {
+    long i = (long)b * F + f;
+    float d = y[i] > 0.0f ? dy[i] : 0.2f * dy[i];
+    dy[i] = d; s += d; q = fmaf(d, xhat[i], q);
+  }
+  sums[f] = s; sums[F + f] = q;
+}
+// part 2: dx = gamma * invstd * (dyh - sums0/n - xhat * sums1/n), sums being global over n rows
+extern "C" __global__ void s2g_k_bn_bwd_apply(const float* __restrict__ dyh, const float* __restrict__ xhat,
+                                              const float* __restrict__ sums, float n_global,
+                                              const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                              float* __restrict__ dx, int B, int F) {
+  int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  float a = sums[f] / n_global, c = sums[F + f] / n_global, gi = gamma[f] * invstd[f];
+  for (int b = 0; b < B; ++b) {
+    long i = (long)b * F + f;
+    dx[i] = gi * (dyh[i] - a - xhat[i] * c);
+  }
+}
+
+// ------------------------------------------------------------------ fused Adam
+// p -= step_size * m / (sqrt(v) * inv_sqrt_bc2 + eps),  step_size = lr / (1 - b1^t),
+// inv_sqrt_bc2 = 1 / sqrt(1 - b2^t)   (torch.optim.Adam, no weight decay / amsgrad).
+// gscale multiplies the gradient first (1/world_size after a SUM all-reduce).
+extern "C" __global__ __launch_bounds__(256) void s2g_k_adam(float* __restrict__ p, const float* __restrict__ g,
+                                                             float* __restrict__ m, float* __restrict__ v, long n,
+                                                             float b1, float b2, float eps, float step_size,
+                                                             float inv_sqrt_bc2, float gscale) {
+  const long n4 = n >> 2;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 P = reinterpret_cast<float4*>(p)[i], G = reinterpret_cast<const float4*>(g)[i];
+    float4 M = reinterpret_cast<float4*>(m)[i], V = reinterpret_cast<float4*>(v)[i];
+#define ADAM1(c)                                                   \
+    { float gg = G.c * gscale;                                     \
+      M.c = b1 * M.c + (1.0f - b1) * gg;                           \
+      V.c = b2 * V.c + (1.0f - b2) * gg * gg;                      \
+      P.c -= step_size * (M.c / (sqrtf(V.c) * inv_sqrt_bc2 + eps)); }
+    ADAM1(x) ADAM1(y) ADAM1(z) ADAM1(w)
+    reinterpret_cast<float4*>(p)[i] = P;
+    reinterpret_cast<float4*>(m)[i] = M;
+    reinterpret_cast<float4*>(v)[i] = V;
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float gg = g[i] * gscale;
+    float mm = b1 * m[i] + (1.0f - b1) * gg;
+    float vv = b2 * v[i] + (1.0f - b2) * gg * gg;
+    m[i] = mm; v[i] = vv;
+    p[i] -= step_size * (mm / (sqrtf(vv) * inv_sqrt_bc2 + eps));
+  }
+}
+
+// ------------------------------------------------------------------ critic weight packing
+// WT0[v][j'] = W_ih0[pt_row(j')][v];  W0p[j'][v] = W_ih0[pt_row(j')][v];
+// b0[j'] = b_ih0 + b_hh0, b1[j'] = b_ih1 + b_hh1 (internal gate order j' = 4*unit + gate)
+extern "C" __global__ void s2g_k_pack_critic(const float* __restrict__ wih0, const float* __restrict__ bih0,
+                                             const float* __restrict__ bhh0, const float* __restrict__ bih1,
+                                             const float* __restrict__ bhh1, float* __restrict__ WT0,
+                                             float* __restrict__ W0p, float* __restrict__ b0,
+                                             float* __restrict__ b1, int V) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < S2G_G * V) {
+    int j = i / V, v = i % V;
+    float w = wih0[(long)pt_row(j) * V + v];
+    W0p[i] = w;
+    WT0[(long)v * S2G_G + j] = w;
+  }
+  if (i < S2G_G) {
+    b0[i] = bih0[pt_row(i)] + bhh0[pt_row(i)];
+    b1[i] = bih1[pt_row(i)] + bhh1[pt_row(i)];
+  }
+}
+
+// x[r][v] = (tokens[r] == v), rows beyond the sequence's length are zero      (wgan_gp.py:277)
+extern "C" __global__ void s2g_k_one_hot(const int* __restrict__ tokens, const int* __restrict__ lengths, int T,
+                                         float* __restrict__ x, long rows, int V) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * V) return;
+  long r = i / V;
+  int v = (int)(i % V);
+  bool live = lengths ? (int)(r % T) < lengths[r / T] : true;
+  x[i] = (live && tokens[r] == v) ? 1.0f : 0.0f;
+}
+
+// x_hat[b][t][v] = alpha_b * onehot(tok[b][t])[v] + (1 - alpha_b) * fake[b][t][v] (0 for t >= Tf)
+// (wgan_gp.py:231-239); rows t >= len_b are written as zero (packing drops them, :241).
+extern "C" __global__ void s2g_k_gp_interp(const int* __restrict__ tokens, const int* __restrict__ lengths,
+                                           const float* __restrict__ fake, const float* __restrict__ alpha, int B,
+                                           int T, int Tf, int V, float* __restrict__ xhat) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * T * V) return;
+  int v = (int)(i % V);
+  long r = i / V;
+  int t = (int)(r % T), b = (int)(r / T);
+  float out = 0.0f;
+  if (t < lengths[b]) {
+    float a = alpha[b];
+    float f = (t < Tf) ? fake[((long)b * Tf + t) * V + v] : 0.0f;
+    out = (tokens[r] == v ? a : 0.0f) + (1.0f - a) * f;
+  }
+  xhat[i] = out;
+}
+
+// Gradient-penalty reduction (wgan_gp.py:255-256) fused with the scaling that seeds the
+// second-order sweeps.  One workgroup per sample b: n_b = |g_b|_2 over its T*V entries,
+// pen[b] = (n_b - 1)^2, then g_b <- coef_b * g_b in place with
+// coef_b = upstream * 2 (n_b - 1) / (n_batch * n_b)   (the direction v_b of sweep C).
+extern "C" __global__ __launch_bounds__(1024) void s2g_k_gp_norm_penalty(float* __restrict__ g, long per_sample,
+                                                                         float upstream, float n_batch,
+                                                                         float* __restrict__ pen,
+                                                                         float* __restrict__ norms, int scale_in_place) {
+  __shared__ float red[16];
+  __shared__ float coef_s;
+  const int b = blockIdx.x;
+  float* gb = g + (long)b * per_sample;
+  float s = 0.0f;
+  const long n4 = per_sample >> 2;
+  for (long i = threadIdx.x; i < n4; i += blockDim.x) {
+    float4 v = reinterpret_cast<const float4*>(gb)[i];
+    s = fmaf(v.x, v.x, s); s = fmaf(v.y, v.y, s); s = fmaf(v.z, v.z, s); s = fmaf(v.w, v.w, s);
+  }
+  for (long i = (n4 << 2) + threadIdx.x; i < per_sample; i += blockDim.x) s = fmaf(gb[i], gb[i], s);
+  s = row16_sum(s);
+  s += __shfl_xor(s, 16);
+  s += __shfl_xor(s, 32);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.0f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += red[w];
+    float nb = sqrtf(tot);
+    pen[b] = (nb - 1.0f) * (nb - 1.0f);
+    if (norms) norms[b] = nb;
+    coef_s = nb > 0.0f ? upstream * 2.0f * (nb - 1.0f) / (n_batch * nb) : 0.0f;
+  }
+  __syncthreads();
+  if (scale_in_place) {
+    const float c = coef_s;
+    for (long i = threadIdx.x; i < n4; i += blockDim.x) {
+      float4 v = reinterpret_cast<float4*>(gb)[i];
+      v.x *= c; v.y *= c; v.z *= c; v.w *= c;
+      reinterpret_cast<float4*>(gb)[i] = v;
+    }
+    for (long i = (n4 << 2) + threadIdx.x; i < per_sample; i += blockDim.x) gb[i] *= c;
+  }
+}
+
+// v_b = coef_b * g_b with coef_b = upstream * 2 (n_b - 1) / (n_batch * n_b), out of place
+// (used when the upstream gradient only becomes known in a later backward call).
+extern "C" __global__ void s2g_k_gp_scale(const float* __restrict__ g, const float* __restrict__ norms,
+                                          const float* __restrict__ upstream, float n_batch, long per_sample,
+                                          float* __restrict__ v, long total) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  float nb = norms[i / per_sample];
+  float c = nb > 0.0f ? upstream[0] * 2.0f * (nb - 1.0f) / (n_batch * nb) : 0.0f;
+  v[i] = c * g[i];
+}
+
+// ------------------------------------------------------------------ critic head and losses
+// out[n][j] = fc.weight[j] . hT[n] + fc.bias[j]                              (wgan_gp.py:220-222)
+extern "C" __global__ void s2g_k_head_fwd(const float* __restrict__ hT, const float* __restrict__ W,
+                                          const float* __restrict__ b, float* __restrict__ out, int N, int J) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * J) return;
+  int n = i / J, j = i % J;
+  float s = b[j];
+  for (int k = 0; k < S2G_H; ++k) s = fmaf(W[j * S2G_H + k], hT[(long)n * S2G_H + k], s);
+  out[i] = s;
+}
+// dhT[n][k] = sum_j dout[n][j] W[j][k]
+extern "C" __global__ void s2g_k_head_bwd_dh(const float* __restrict__ dout, const float* __restrict__ W,
+                                             float* __restrict__ dhT, int N, int J) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * S2G_H) return;
+  int n = i / S2G_H, k = i % S2G_H;
+  float s = 0.0f;
+  for (int j = 0; j < J; ++j) s = fmaf(dout[n * J + j], W[j * S2G_H + k], s);
+  dhT[i] = s;
+}
+// dW[j][k] (+)= sum_n dout[n][j] hT[n][k];  db[j] (+)= sum_n dout[n][j]     (one thread per (j,k))
+extern "C" __global__ void s2g_k_head_bwd_w(const float* __restrict__ dout, const float* __restrict__ hT,
+                                            float* __restrict__ dW, float* __restrict__ db, int N, int J,
+                                            int accumulate) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= J * S2G_H) return;
+  int j = i / S2G_H, k = i % S2G_H;
+  float s = 0.0f, sb = 0.0f;
+  for (int n = 0; n < N; ++n) {
+    float d = dout[n * J + j];
+    s = fmaf(d, hT[(long)n * S2G_H + k], s);
+    sb += d;
+  }
+  dW[i] = accumulate ? dW[i] + s : s;
+  if (k == 0) db[j] = accumulate ? db[j] + sb : sb;
+}
+
+// CrossEntropyLoss(weight=[w0,w1]) applied to p = softmax(z) (probabilities fed as logits, the
+// reference's double softmax, wgan_gp.py:268,299,310): per-sample value and d/dz.
+__device__ __forceinline__ void ce_on_probs(float z0, float z1, int y, float w0, float w1, float inv_wsum,
+                                            float& loss, float& dz0, float& dz1) {
+  float m = fmaxf(z0, z1);
+  float e0 = expf(z0 - m), e1 = expf(z1 - m);
+  float p0 = e0 / (e0 + e1), p1 = e1 / (e0 + e1);
+  float m2 = fmaxf(p0, p1);
+  float f0 = expf(p0 - m2), f1 = expf(p1 - m2);
+  float lse = m2 + logf(f0 + f1);
+  float s0 = f0 / (f0 + f1), s1 = f1 / (f0 + f1);        // softmax(p)
+  float wy = (y == 0 ? w0 : w1) * inv_wsum;
+  loss = wy * (lse - (y == 0 ? p0 : p1));
+  float dp0 = wy * (s0 - (y == 0 ? 1.0f : 0.0f)), dp1 = wy * (s1 - (y == 1 ? 1.0f : 0.0f));
+  float dot = dp0 * p0 + dp1 * p1;
+  dz0 = p0 * (dp0 - dot);
+  dz1 = p1 * (dp1 - dot);
+}
+
+// Critic loss terms and d(out) for a batch laid out [real B | fake B | interp B]
+// (wgan_gp.py:298-315).  out: [3B,3].  inv_n = 1/B_global, inv_wsum = 1/sum_b w[y_b] (global).
+//   dout_real = (-inv_n, 0.5 dCE), dout_fake = (+inv_n, 0.5 dCE), dout_interp = (1, 0, 0)
+//   losses[0] = -sum real_validity*inv_n, [1] = sum fake_validity*inv_n, [2] = 0.5*(CE_r+CE_f)
+// Single workgroup; B <= 1024.
+extern "C" __global__ __launch_bounds__(1024) void s2g_k_critic_loss(const float* __restrict__ out,
+                                                                     const long long* __restrict__ labels, int B,
+                                                                     float inv_n, float inv_wsum, float w0,
+                                                                     float w1, float* __restrict__ dout,
+                                                                     float* __restrict__ losses) {
+  __shared__ float red[3][16];
+  const int b = threadIdx.x;
+  float lr = 0.f, lf = 0.f, lce = 0.f;
+  if (b < B) {
+    int y = (int)labels[b];
+    float l, d0, d1;
+    const float* o = out + b * 3;
+    ce_on_probs(o[1], o[2], y, w0, w1, inv_wsum, l, d0, d1);
+    dout[b * 3 + 0] = -inv_n; dout[b * 3 + 1] = 0.5f * d0; dout[b * 3 + 2] = 0.5f * d1;
+    lr = -o[0] * inv_n; lce = 0.5f * l;
+    o = out + (B + b) * 3;
+    ce_on_probs(o[1], o[2], y, w0, w1, inv_wsum, l, d0, d1);
+    dout[(B + b) * 3 + 0] = inv_n; dout[(B + b) * 3 + 1] = 0.5f * d0; dout[(B + b) * 3 + 2] = 0.5f * d1;
+    lf = o[0] * inv_n; lce += 0.5f * l;
+    dout[(2 * B + b) * 3 + 0] = 1.0f; dout[(2 * B + b) * 3 + 1] = 0.0f; dout[(2 * B + b) * 3 + 2] = 0.0f;
+  }
+  lr = row16_sum(lr); lr += __shfl_xor(lr, 16); lr += __shfl_xor(lr, 32);
+  lf = row16_sum(lf); lf += __shfl_xor(lf, 16); lf += __shfl_xor(lf, 32);
+  lce = row16_sum(lce); lce += __shfl_xor(lce, 16); lce += __shfl_xor(lce, 32);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = lr; red[1][threadIdx.x >> 6] = lf; red[2][threadIdx.x >> 6] = lce; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    float s = 0.0f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[threadIdx.x][w];
+    losses[threadIdx.x] = s;
+  }
+}
+
+// Generator loss (wgan_gp.py:333-340): g_loss = -mean(validity) + 0.5 * (0.5 * CE).
+// out: [B,3];  dout = (-inv_n, 0.25 dCE);  losses[0] = -sum validity*inv_n, losses[1] = 0.25*CE.
+extern "C" __global__ __launch_bounds__(1024) void s2g_k_generator_loss(const float* __restrict__ out,
+                                                                        const long long* __restrict__ labels, int B,
+                                                                        float inv_n, float inv_wsum, float w0,
+                                                                        float w1, float* __restrict__ dout,
+                                                                        float* __restrict__ losses) {
+  __shared__ float red[2][16];
+  const int b = threadIdx.x;
+  float lv = 0.f, lce = 0.f;
+  if (b < B) {
+    float l, d0, d1;
+    const float* o = out + b * 3;
+    ce_on_probs(o[1], o[2], (int)labels[b], w0, w1, inv_wsum, l, d0, d1);
+    dout[b * 3 + 0] = -inv_n; dout[b * 3 + 1] = 0.25f * d0; dout[b * 3 + 2] = 0.25f * d1;
+    lv = -o[0] * inv_n; lce = 0.25f * l;
+  }
+  lv = row16_sum(lv); lv += __shfl_xor(lv, 16); lv += __shfl_xor(lv, 32);
+  lce = row16_sum(lce); lce += __shfl_xor(lce, 16); lce += __shfl_xor(lce, 32);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = lv; red[1][threadIdx.x >> 6] = lce; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    float s = 0.0f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[threadIdx.x][w];
+    losses[threadIdx.x] = s;
+  }
+}
+
+// Sequence descriptors for the fused critic batch [real B | fake B | interp B]:
+//   real   : tokens, len = lengths[b]
+//   fake   : projection rows b*Tf.., len = Tf                       (dense call, wgan_gp.py:302)
+//   interp : alpha*tokens + (1-alpha)*projection rows (t < Tf), len = lengths[b]   (:239-241)
+// followed by a 4th group repeating interp with group-relative rows.  seqs holds 4B entries.
+// use_mask: dropout-mask rows coincide with workspace rows.
+extern "C" __global__ void s2g_k_critic_batch_desc(const int* __restrict__ lengths, const float* __restrict__ alpha,
+                                                   int B, int T, int Tf, int use_mask, S2GSeq* __restrict__ seqs) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 4 * B) return;
+  int kind = i / B, b = i % B;
+  const int Tw = T > Tf ? T : Tf;     // workspace rows per sequence
+  S2GSeq s;
+  // kind 3 repeats the interp sequences with rows counted from the first interp row, for the
+  // second-order sweeps whose buffers hold the interp sequences only
+  const int r0 = (kind == 3 ? b : i) * Tw;
+  s.ws_row = r0;
+  s.mask_off = use_mask ? r0 : -1;
+  if (kind == 0) {
+    s.len = lengths[b]; s.tok_off = b * T; s.p_off = -1; s.p_len = 0; s.ca = 1.0f; s.cp = 0.0f;
+  } else if (kind == 1) {
+    s.len = Tf; s.tok_off = -1; s.p_off = b * Tf; s.p_len = Tf; s.ca = 0.0f; s.cp = 1.0f;
+  } else {
+    float a = alpha[b];
+    s.len = lengths[b]; s.tok_off = b * T; s.p_off = b * Tf; s.p_len = Tf; s.ca = a; s.cp = 1.0f - a;
+  }
+  seqs[i] = s;
+}

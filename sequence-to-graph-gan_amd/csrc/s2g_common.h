@@ -1,0 +1,73 @@
+// Shared device helpers for the gfx950 kernels of the WGAN-GP step.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define S2G_H 50          // critic hidden size (wgan_gp.py:394)
+#define S2G_G 200         // 4*H gate rows
+#define S2G_MASKW 52      // dropout-mask row width: H padded to a multiple of 4 (16-byte rows)
+
+// Internal gate order: row j' = 4*unit + q with q = 0:i 1:f 2:g 3:o.  torch.nn.LSTM stores
+// row j = q*H + unit (gate blocks i|f|g|o); pt_row() maps internal -> torch.
+__host__ __device__ inline int pt_row(int jint) { return (jint & 3) * S2G_H + (jint >> 2); }
+
+// One sequence of a critic batch.  xproj_t = ca * WT[token_t] + cp * P[p_off + t] (t < p_len) + b0
+struct S2GSeq {
+  int len;        // live steps
+  int tok_off;    // offset of this sequence's tokens (int32) or -1
+  int p_off;      // first row of this sequence in the projection buffer P, or -1
+  int p_len;      // rows of P that exist for it
+  float ca;       // coefficient on the gathered row of W_ih0^T
+  float cp;       // coefficient on the projection row
+  int mask_off;   // first row in the dropout-mask buffer [rows, 52], or -1
+  int ws_row;     // first row of this sequence in every workspace
+};
+
+// ---- DPP cross-lane helpers (64-wide wave, 16-lane DPP rows) ---------------------------------
+#define DPP_QUAD(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
+#define DPP_ROW_MIRROR 0x140
+#define DPP_ROW_HALF_MIRROR 0x141
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  int r = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true);
+  return __builtin_bit_cast(float, r);
+}
+// sum over the 4 lanes of a quad; every lane gets the total
+__device__ __forceinline__ float quad_sum(float v) {
+  v += dpp_mov<DPP_QUAD(1, 0, 3, 2)>(v);
+  v += dpp_mov<DPP_QUAD(2, 3, 0, 1)>(v);
+  return v;
+}
+// sum over the 16 lanes of a DPP row; every lane gets the total
+__device__ __forceinline__ float row16_sum(float v) {
+  v = quad_sum(v);
+  v += dpp_mov<DPP_ROW_HALF_MIRROR>(v);
+  v += dpp_mov<DPP_ROW_MIRROR>(v);
+  return v;
+}
+template <int L>
+__device__ __forceinline__ float quad_bcast(float v) {
+  return dpp_mov<DPP_QUAD(L, L, L, L)>(v);
+}
+
+// ---- activations -----------------------------------------------------------------------------
+// sigma(x) = 1/(1+2^(-x*log2 e)); tanh(x) = 2*sigma(2x)-1.  v_exp_f32 / v_rcp_f32 are ~1 ulp.
+__device__ __forceinline__ float fast_sigmoid(float x) {
+  float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * x);
+  return __builtin_amdgcn_rcpf(1.0f + e);
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+  float e = __builtin_amdgcn_exp2f(-2.8853900817779268f * x);
+  return 2.0f * __builtin_amdgcn_rcpf(1.0f + e) - 1.0f;
+}
+
+// storage position of hidden unit k (or gate row j) in an LDS vector cut into slices of 13
+// values, each slice padded to 16 floats so a lane fetches its slice with 16-byte reads
+__device__ __forceinline__ int pos13(int k) { return ((k / 13) << 4) + (k % 13); }
+
+#define S2G_CHECK(expr)                                   \
+  do {                                                    \
+    hipError_t _e = (expr);                               \
+    if (_e != hipSuccess) return -(int)_e - 1000;         \
+  } while (0)

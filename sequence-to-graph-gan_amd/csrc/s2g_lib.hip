@@ -1,0 +1,257 @@
+// Host side of libs2g: argument checks + kernel launches behind the C ABI of include/s2g.h.
+// Single translation unit: the kernel files are included so every launch sees its kernel.
+#include "s2g_common.h"
+#include "lstm_fwd.hip"
+#include "lstm_bwd.hip"
+#include "gemm.hip"
+#include "sampler.hip"
+#include "elementwise.hip"
+#include <math.h>
+
+#define ST(s) ((hipStream_t)(s))
+#define LAUNCH_OK() (hipGetLastError() == hipSuccess ? 0 : -2)
+static inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }
+
+extern "C" {
+
+int s2g_version(void) { return 100; }
+
+int s2g_gumbel_softmax_fwd(const float* logits, const float* U, const float* bias, int bias_rows, float* y_out,
+                           float* y_soft, long rows, int V, float tau, int mode, int hard, void* stream) {
+  if (!logits || !y_out || rows <= 0 || V <= 0 || V > 64 * MAXPER || mode < 0 || mode > 2) return -1;
+  if (mode == 0 && !U) return -1;
+  if (mode != 2 && !(tau > 0.0f)) return -1;
+  if (hard && !y_soft) return -1;
+  if (bias && bias_rows <= 0) return -1;
+  hipLaunchKernelGGL(s2g_k_gumbel_softmax_fwd, dim3(cdiv(rows, 4)), dim3(256), 0, ST(stream), logits, U, bias,
+                     bias_rows, y_out, y_soft, rows, V, 1.0f / tau, mode, hard);
+  return LAUNCH_OK();
+}
+
+int s2g_gumbel_softmax_bwd(const float* y_soft, const float* dy, float* dlogits, long rows, int V, float scale,
+                           void* stream) {
+  if (!y_soft || !dy || !dlogits || rows <= 0 || V <= 0 || V > 64 * MAXPER) return -1;
+  hipLaunchKernelGGL(s2g_k_gumbel_softmax_bwd, dim3(cdiv(rows, 4)), dim3(256), 0, ST(stream), y_soft, dy,
+                     dlogits, rows, V, scale);
+  return LAUNCH_OK();
+}
+
+int s2g_argmax_rows(const float* y, long long* tokens, long rows, int V, void* stream) {
+  if (!y || !tokens || rows <= 0 || V <= 0) return -1;
+  hipLaunchKernelGGL(s2g_k_argmax_rows, dim3(cdiv(rows, 4)), dim3(256), 0, ST(stream), y, tokens, rows, V);
+  return LAUNCH_OK();
+}
+
+int s2g_gemm_f32(const GemmArgs* args, int nsplit, void* stream) {
+  if (!args || !args->A || !args->B || !args->C) return -1;
+  if (args->segT < 0 || (args->shift && args->segT <= 0)) return -1;
+  return s2g_launch_gemm(args, nsplit, ST(stream));
+}
+
+int s2g_reduce_slabs(const float* slabs, long slab, int nslab, int rows, int cols, float* out, int permute_rows,
+                     int accumulate, float scale, void* stream) {
+  if (!slabs || !out || nslab <= 0 || rows <= 0 || cols <= 0) return -1;
+  if (permute_rows && rows != S2G_G) return -1;
+  hipLaunchKernelGGL(s2g_k_reduce_slabs, dim3(cdiv((long)rows * cols, 256)), dim3(256), 0, ST(stream), slabs,
+                     slab, nslab, rows, cols, out, permute_rows, accumulate, scale);
+  return LAUNCH_OK();
+}
+
+int s2g_colsum(const float* X, long ld, long rows, int cols, float* part, long rows_per_chunk, void* stream) {
+  if (!X || !part || rows <= 0 || cols <= 0 || rows_per_chunk <= 0) return -1;
+  hipLaunchKernelGGL(s2g_k_colsum, dim3(cdiv(cols, 64), cdiv(rows, rows_per_chunk)), dim3(256), 0, ST(stream), X,
+                     ld, rows, cols, part, rows_per_chunk);
+  return LAUNCH_OK();
+}
+
+int s2g_lstm2_fwd(const S2GSeq* seqs, int nseq, int max_len, const int* tokens, const float* WT0, const float* P,
+                  const float* mask, const float* b0, const float* b1, const float* whh0, const float* wih1,
+                  const float* whh1, float* gates0, float* cell0, float* gates1, float* cell1, float* hT,
+                  void* stream) {
+  if (!seqs || nseq <= 0 || max_len < 0 || max_len > 16384) return -1;
+  if (!b0 || !b1 || !whh0 || !wih1 || !whh1 || !gates0 || !cell0 || !gates1 || !cell1 || !hT) return -1;
+  size_t lds = 384 * sizeof(float) + (size_t)max_len * sizeof(int);
+  hipLaunchKernelGGL(s2g_k_lstm2_fwd, dim3(nseq), dim3(512), lds, ST(stream), seqs, tokens, WT0, P, mask, b0, b1,
+                     whh0, wih1, whh1, gates0, cell0, gates1, cell1, hT);
+  return LAUNCH_OK();
+}
+
+int s2g_lstm2_bwd(const S2GSeq* seqs, int nseq, int rows_per_seq, const float* mask, const float* whh0,
+                  const float* wih1, const float* whh1, const float* gates0, const float* cell0,
+                  const float* gates1, const float* cell1, const float* dhT, float* delta0, float* delta1,
+                  float* adj0, float* adj1, int adj_seq0, int adj_row0, void* stream) {
+  if (!seqs || nseq <= 0 || rows_per_seq <= 0) return -1;
+  if (!whh0 || !wih1 || !whh1 || !gates0 || !cell0 || !gates1 || !cell1 || !dhT || !delta0 || !delta1) return -1;
+  if ((adj0 == nullptr) != (adj1 == nullptr)) return -1;
+  if (adj0 && (adj_seq0 < 0 || adj_row0 < 0)) return -1;
+  hipLaunchKernelGGL(s2g_k_lstm2_bwd, dim3(nseq), dim3(512), 0, ST(stream), seqs, mask, whh0, wih1, whh1, gates0,
+                     cell0, gates1, cell1, dhT, delta0, delta1, adj0, adj1, rows_per_seq, adj_seq0, adj_row0);
+  return LAUNCH_OK();
+}
+
+int s2g_lstm2_tangent(const S2GSeq* seqs, int nseq, const float* Xdot, const float* mask, const float* whh0,
+                      const float* wih1, const float* whh1, const float* gates0, const float* cell0,
+                      const float* gates1, const float* cell1, float* adot0, float* celld0, float* adot1,
+                      float* celld1, float* hdotT, void* stream) {
+  if (!seqs || nseq <= 0 || !Xdot) return -1;
+  if (!whh0 || !wih1 || !whh1 || !gates0 || !cell0 || !gates1 || !cell1) return -1;
+  if (!adot0 || !celld0 || !adot1 || !celld1 || !hdotT) return -1;
+  hipLaunchKernelGGL(s2g_k_lstm2_tangent, dim3(nseq), dim3(512), 0, ST(stream), seqs, Xdot, mask, whh0, wih1,
+                     whh1, gates0, cell0, gates1, cell1, adot0, celld0, adot1, celld1, hdotT);
+  return LAUNCH_OK();
+}
+
+int s2g_lstm2_bwd2(const S2GSeq* seqs, int nseq, int rows_per_seq, const float* mask, const float* whh0,
+                   const float* wih1, const float* whh1, const float* gates0, const float* cell0,
+                   const float* gates1, const float* cell1, const float* adot0, const float* celld0,
+                   const float* adot1, const float* celld1, const float* adj0, const float* adj1, float* abar0,
+                   float* abar1, void* stream) {
+  if (!seqs || nseq <= 0 || rows_per_seq <= 0) return -1;
+  if (!whh0 || !wih1 || !whh1 || !gates0 || !cell0 || !gates1 || !cell1) return -1;
+  if (!adot0 || !celld0 || !adot1 || !celld1 || !adj0 || !adj1 || !abar0 || !abar1) return -1;
+  hipLaunchKernelGGL(s2g_k_lstm2_bwd2, dim3(nseq), dim3(512), 0, ST(stream), seqs, mask, whh0, wih1, whh1, gates0,
+                     cell0, gates1, cell1, adot0, celld0, adot1, celld1, adj0, adj1, abar0, abar1, rows_per_seq);
+  return LAUNCH_OK();
+}
+
+int s2g_pack_critic(const float* wih0, const float* bih0, const float* bhh0, const float* bih1, const float* bhh1,
+                    float* WT0, float* W0p, float* b0, float* b1, int V, void* stream) {
+  if (!wih0 || !bih0 || !bhh0 || !bih1 || !bhh1 || !WT0 || !W0p || !b0 || !b1 || V <= 0) return -1;
+  hipLaunchKernelGGL(s2g_k_pack_critic, dim3(cdiv((long)S2G_G * V, 256)), dim3(256), 0, ST(stream), wih0, bih0,
+                     bhh0, bih1, bhh1, WT0, W0p, b0, b1, V);
+  return LAUNCH_OK();
+}
+
+int s2g_critic_batch_desc(const int* lengths, const float* alpha, int B, int T, int Tf, int use_mask, S2GSeq* seqs,
+                          void* stream) {
+  if (!lengths || !alpha || !seqs || B <= 0 || T <= 0 || Tf <= 0) return -1;
+  hipLaunchKernelGGL(s2g_k_critic_batch_desc, dim3(cdiv(4 * B, 256)), dim3(256), 0, ST(stream), lengths, alpha, B,
+                     T, Tf, use_mask, seqs);
+  return LAUNCH_OK();
+}
+
+int s2g_head_fwd(const float* hT, const float* W, const float* b, float* out, int N, int J, void* stream) {
+  if (!hT || !W || !b || !out || N <= 0 || J <= 0) return -1;
+  hipLaunchKernelGGL(s2g_k_head_fwd, dim3(cdiv((long)N * J, 256)), dim3(256), 0, ST(stream), hT, W, b, out, N, J);
+  return LAUNCH_OK();
+}
+int s2g_head_bwd_dh(const float* dout, const float* W, float* dhT, int N, int J, void* stream) {
+  if (!dout || !W || !dhT || N <= 0 || J <= 0) return -1;
+  hipLaunchKernelGGL(s2g_k_head_bwd_dh, dim3(cdiv((long)N * S2G_H, 256)), dim3(256), 0, ST(stream), dout, W, dhT,
+                     N, J);
+  return LAUNCH_OK();
+}
+int s2g_head_bwd_w(const float* dout, const float* hT, float* dW, float* db, int N, int J, int accumulate,
+                   void* stream) {
+  if (!dout || !hT || !dW || !db || N <= 0 || J <= 0) return -1;
+  hipLaunchKernelGGL(s2g_k_head_bwd_w, dim3(cdiv((long)J * S2G_H, 64)), dim3(64), 0, ST(stream), dout, hT, dW, db,
+                     N, J, accumulate);
+  return LAUNCH_OK();
+}
+int s2g_critic_loss(const float* out, const long long* labels, int B, float inv_n, float inv_wsum, float w0,
+                    float w1, float* dout, float* losses, void* stream) {
+  if (!out || !labels || !dout || !losses || B <= 0 || B > 1024) return -1;
+  hipLaunchKernelGGL(s2g_k_critic_loss, dim3(1), dim3(cdiv(B, 64) * 64), 0, ST(stream), out, labels, B, inv_n,
+                     inv_wsum, w0, w1, dout, losses);
+  return LAUNCH_OK();
+}
+int s2g_generator_loss(const float* out, const long long* labels, int B, float inv_n, float inv_wsum, float w0,
+                       float w1, float* dout, float* losses, void* stream) {
+  if (!out || !labels || !dout || !losses || B <= 0 || B > 1024) return -1;
+  hipLaunchKernelGGL(s2g_k_generator_loss, dim3(1), dim3(cdiv(B, 64) * 64), 0, ST(stream), out, labels, B, inv_n,
+                     inv_wsum, w0, w1, dout, losses);
+  return LAUNCH_OK();
+}
+
+int s2g_one_hot(const int* tokens, const int* lengths, int T, float* x, long rows, int V, void* stream) {
+  if (!tokens || !x || rows <= 0 || V <= 0 || (lengths && T <= 0)) return -1;
+  hipLaunchKernelGGL(s2g_k_one_hot, dim3(cdiv(rows * V, 256)), dim3(256), 0, ST(stream), tokens, lengths, T, x,
+                     rows, V);
+  return LAUNCH_OK();
+}
+int s2g_gp_interp(const int* tokens, const int* lengths, const float* fake, const float* alpha, int B, int T,
+                  int Tf, int V, float* xhat, void* stream) {
+  if (!tokens || !lengths || !fake || !alpha || !xhat || B <= 0 || T <= 0 || Tf <= 0 || V <= 0) return -1;
+  hipLaunchKernelGGL(s2g_k_gp_interp, dim3(cdiv((long)B * T * V, 256)), dim3(256), 0, ST(stream), tokens, lengths,
+                     fake, alpha, B, T, Tf, V, xhat);
+  return LAUNCH_OK();
+}
+int s2g_gp_norm_penalty(float* g, int B, long per_sample, float upstream, float n_batch, float* pen, float* norms,
+                        int scale_in_place, void* stream) {
+  if (!g || !pen || B <= 0 || per_sample <= 0 || !(n_batch > 0.0f)) return -1;
+  if ((per_sample * sizeof(float)) % 16 != 0) return -1;   // float4 rows
+  hipLaunchKernelGGL(s2g_k_gp_norm_penalty, dim3(B), dim3(1024), 0, ST(stream), g, per_sample, upstream, n_batch,
+                     pen, norms, scale_in_place);
+  return LAUNCH_OK();
+}
+int s2g_gp_scale(const float* g, const float* norms, const float* upstream, float n_batch, long per_sample,
+                 float* v, int B, void* stream) {
+  if (!g || !norms || !upstream || !v || B <= 0 || per_sample <= 0) return -1;
+  long total = (long)B * per_sample;
+  hipLaunchKernelGGL(s2g_k_gp_scale, dim3(cdiv(total, 256)), dim3(256), 0, ST(stream), g, norms, upstream, n_batch,
+                     per_sample, v, total);
+  return LAUNCH_OK();
+}
+
+int s2g_embed_mul(const float* z, const long long* labels, const float* emb, float* out, int B, int D,
+                  void* stream) {
+  if (!z || !labels || !emb || !out || B <= 0 || D <= 0) return -1;
+  hipLaunchKernelGGL(s2g_k_embed_mul, dim3(cdiv((long)B * D, 256)), dim3(256), 0, ST(stream), z, labels, emb, out,
+                     B, D);
+  return LAUNCH_OK();
+}
+int s2g_embed_mul_bwd(const float* z, const long long* labels, const float* dout, float* demb, int B, int D,
+                      int n_classes, void* stream) {
+  if (!z || !labels || !dout || !demb || B <= 0 || D <= 0 || n_classes <= 0) return -1;
+  hipLaunchKernelGGL(s2g_k_embed_mul_bwd, dim3(cdiv((long)n_classes * D, 256)), dim3(256), 0, ST(stream), z,
+                     labels, dout, demb, B, D, n_classes);
+  return LAUNCH_OK();
+}
+int s2g_lrelu_bwd(const float* y, float* dy, long n, void* stream) {
+  if (!y || !dy || n <= 0) return -1;
+  hipLaunchKernelGGL(s2g_k_lrelu_bwd, dim3(cdiv(n, 256)), dim3(256), 0, ST(stream), y, dy, n);
+  return LAUNCH_OK();
+}
+int s2g_bn_stats(const float* x, float* stats, int B, int F, void* stream) {
+  if (!x || !stats || B <= 0 || F <= 0) return -1;
+  hipLaunchKernelGGL(s2g_k_bn_stats, dim3(cdiv(F, 64)), dim3(64), 0, ST(stream), x, stats, B, F);
+  return LAUNCH_OK();
+}
+int s2g_bn_lrelu_apply(const float* x, const float* stats, float n_global, const float* gamma, const float* beta,
+                       float* run_mean, float* run_var, float eps, float momentum, int update_running, float* y,
+                       float* xhat, float* invstd, int B, int F, void* stream) {
+  if (!x || !gamma || !beta || !run_mean || !run_var || !y || B <= 0 || F <= 0) return -1;
+  if (stats && !(n_global > 0.0f)) return -1;
+  hipLaunchKernelGGL(s2g_k_bn_lrelu_apply, dim3(cdiv(F, 64)), dim3(64), 0, ST(stream), x, stats, n_global, gamma,
+                     beta, run_mean, run_var, eps, momentum, update_running, y, xhat, invstd, B, F);
+  return LAUNCH_OK();
+}
+int s2g_bn_lrelu_bwd_stats(const float* y, float* dy, const float* xhat, float* sums, int B, int F, void* stream) {
+  if (!y || !dy || !xhat || !sums || B <= 0 || F <= 0) return -1;
+  hipLaunchKernelGGL(s2g_k_bn_lrelu_bwd_stats, dim3(cdiv(F, 64)), dim3(64), 0, ST(stream), y, dy, xhat, sums, B, F);
+  return LAUNCH_OK();
+}
+int s2g_bn_bwd_apply(const float* dyh, const float* xhat, const float* sums, float n_global, const float* gamma,
+                     const float* invstd, float* dx, int B, int F, void* stream) {
+  if (!dyh || !xhat || !sums || !gamma || !invstd || !dx || B <= 0 || F <= 0 || !(n_global > 0.0f)) return -1;
+  hipLaunchKernelGGL(s2g_k_bn_bwd_apply, dim3(cdiv(F, 64)), dim3(64), 0, ST(stream), dyh, xhat, sums, n_global,
+                     gamma, invstd, dx, B, F);
+  return LAUNCH_OK();
+}
+
+int s2g_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+             int step, float gscale, void* stream) {
+  if (!p || !g || !m || !v || n <= 0 || step < 1) return -1;
+  if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return -1;
+  const double bc1 = 1.0 - pow((double)b1, (double)step);
+  const double bc2 = 1.0 - pow((double)b2, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  unsigned blocks = cdiv(n, 1024);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(s2g_k_adam, dim3(blocks), dim3(256), 0, ST(stream), p, g, m, v, n, b1, b2, eps, step_size,
+                     inv_sqrt_bc2, gscale);
+  return LAUNCH_OK();
+}
+
+}  // extern "C"

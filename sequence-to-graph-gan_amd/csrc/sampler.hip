@@ -1,0 +1,136 @@
+// Fused Gumbel-softmax sampler over the vocabulary axis (reference: CustomSoftmax,
+// wgan_gp.py:36-104).  One 64-lane wavefront per row of V logits (V = 175 -> 3 values per
+// lane); max and sum are reduced with DPP inside each 16-lane row and two cross-row shuffles.
+#include "s2g_common.h"
+
+#define MAXPER 8   // supports V <= 512
+
+__device__ __forceinline__ float wave_max(float v) {
+  v = fmaxf(v, dpp_mov<DPP_QUAD(1, 0, 3, 2)>(v));
+  v = fmaxf(v, dpp_mov<DPP_QUAD(2, 3, 0, 1)>(v));
+  v = fmaxf(v, dpp_mov<DPP_ROW_HALF_MIRROR>(v));
+  v = fmaxf(v, dpp_mov<DPP_ROW_MIRROR>(v));
+  v = fmaxf(v, __shfl_xor(v, 16));
+  v = fmaxf(v, __shfl_xor(v, 32));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v = row16_sum(v);
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+
+// mode 0: gumbel (wgan_gp.py:56-86)   y = softmax((logits + g(U)) / tau)
+// mode 1: relaxed (wgan_gp.py:94-104) y = softmax(logits / tau)
+// mode 2: plain   (wgan_gp.py:54)     y = softmax(logits)
+// hard: y_out = one_hot(argmax y) (first maximal index, as torch.argmax); y_soft keeps the soft
+// sample, which is what the straight-through backward differentiates (wgan_gp.py:80-84).
+// bias (optional, [V * rows_per_bias-cycle]) is added to the logits first: lets the generator's
+// last Linear skip its own bias pass (bias index = (row % bias_rows) * V + j).
+extern "C" __global__ __launch_bounds__(256) void s2g_k_gumbel_softmax_fwd(
+    const float* __restrict__ logits, const float* __restrict__ U, const float* __restrict__ bias,
+    int bias_rows, float* __restrict__ y_out, float* __restrict__ y_soft, long rows, int V,
+    float inv_tau, int mode, int hard) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* lg = logits + row * V;
+  const float* bs = bias ? bias + (row % bias_rows) * V : nullptr;
+  float z[MAXPER];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int e = 0; e < MAXPER; ++e) {
+    int j = lane + 64 * e;
+    z[e] = -INFINITY;
+    if (j < V) {
+      float x = lg[j];
+      if (bs) x += bs[j];
+      if (mode == 0) {
+        float u = 1e-10f + (1.0f - 1e-10f) * U[row * V + j];
+        x += -logf(-logf(u + 1e-20f) + 1e-20f);
+      }
+      z[e] = (mode == 2) ? x : x * inv_tau;
+      mx = fmaxf(mx, z[e]);
+    }
+  }
+  mx = wave_max(mx);
+  float sum = 0.0f;
+#pragma unroll
+  for (int e = 0; e < MAXPER; ++e) {
+    int j = lane + 64 * e;
+    z[e] = (j < V) ? expf(z[e] - mx) : 0.0f;
+    sum += z[e];
+  }
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum;
+  int best = 0x7fffffff;
+  if (hard) {
+    // soft probabilities can tie after rounding; torch takes the first index of the maximum
+    float bv = -1.0f;
+#pragma unroll
+    for (int e = 0; e < MAXPER; ++e) {
+      int j = lane + 64 * e;
+      float p = z[e] * inv;
+      if (j < V && p > bv) { bv = p; best = j; }
+    }
+    float wm = wave_max(bv);
+    int cand = (bv == wm) ? best : 0x7fffffff;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) cand = min(cand, __shfl_xor(cand, o));
+    best = cand;
+  }
+#pragma unroll
+  for (int e = 0; e < MAXPER; ++e) {
+    int j = lane + 64 * e;
+    if (j < V) {
+      float p = z[e] * inv;
+      if (y_soft) y_soft[row * V + j] = p;
+      y_out[row * V + j] = hard ? (j == best ? 1.0f : 0.0f) : p;
+    }
+  }
+}
+
+// dlogits = s * y * (dy - <dy, y>) with s = 1/tau (modes 0,1) or 1 (mode 2); y = soft sample.
+extern "C" __global__ __launch_bounds__(256) void s2g_k_gumbel_softmax_bwd(
+    const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dlogits, long rows,
+    int V, float scale) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float yv[MAXPER], dv[MAXPER];
+  float dot = 0.0f;
+#pragma unroll
+  for (int e = 0; e < MAXPER; ++e) {
+    int j = lane + 64 * e;
+    yv[e] = 0.f; dv[e] = 0.f;
+    if (j < V) { yv[e] = y[row * V + j]; dv[e] = dy[row * V + j]; }
+    dot = fmaf(yv[e], dv[e], dot);
+  }
+  dot = wave_sum(dot);
+#pragma unroll
+  for (int e = 0; e < MAXPER; ++e) {
+    int j = lane + 64 * e;
+    if (j < V) dlogits[row * V + j] = scale * yv[e] * (dv[e] - dot);
+  }
+}
+
+// tokens[row] = argmax_j y[row][j]  (generate_fake_data.py:66), first maximal index.
+extern "C" __global__ __launch_bounds__(256) void s2g_k_argmax_rows(const float* __restrict__ y,
+                                                                    long long* __restrict__ tokens,
+                                                                    long rows, int V) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float bv = -INFINITY;
+  int best = 0x7fffffff;
+  for (int j = lane; j < V; j += 64) {
+    float p = y[row * V + j];
+    if (p > bv) { bv = p; best = j; }
+  }
+  float wm = wave_max(bv);
+  int cand = (bv == wm) ? best : 0x7fffffff;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) cand = min(cand, __shfl_xor(cand, o));
+  if (lane == 0) tokens[row] = cand;
+}

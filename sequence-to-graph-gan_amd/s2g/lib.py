@@ -1,0 +1,94 @@
+"""ctypes binding of libs2g.so (the C ABI declared in include/s2g.h).
+
+The library is the product path: if it is missing or a symbol is absent the import fails
+loudly -- there is no PyTorch fallback for any of these entry points."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libs2g.so")
+
+P, I, L, F = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
+
+
+class S2GSeq(ctypes.Structure):
+    _fields_ = [("len", I), ("tok_off", I), ("p_off", I), ("p_len", I), ("ca", F), ("cp", F),
+                ("mask_off", I), ("ws_row", I)]
+
+
+class S2GGemm(ctypes.Structure):
+    _fields_ = [("A", P), ("sam", L), ("sak", L), ("B", P), ("sbk", L), ("sbn", L), ("C", P), ("ldc", L),
+                ("slab", L), ("bias", P), ("M", I), ("N", I), ("K", I), ("kchunk", I), ("segT", I),
+                ("a_seg", I), ("b_seg", I), ("shift", I), ("accumulate", I), ("act", I), ("alpha", F)]
+
+
+# name -> argument types (every function returns int and takes the stream last)
+SIGNATURES = {
+    "s2g_version": [],
+    "s2g_gumbel_softmax_fwd": [P, P, P, I, P, P, L, I, F, I, I, P],
+    "s2g_gumbel_softmax_bwd": [P, P, P, L, I, F, P],
+    "s2g_argmax_rows": [P, P, L, I, P],
+    "s2g_gemm_f32": [ctypes.POINTER(S2GGemm), I, P],
+    "s2g_reduce_slabs": [P, L, I, I, I, P, I, I, F, P],
+    "s2g_colsum": [P, L, L, I, P, L, P],
+    "s2g_lstm2_fwd": [P, I, I] + [P] * 15,
+    "s2g_lstm2_bwd": [P, I, I] + [P] * 13 + [I, I, P],
+    "s2g_lstm2_tangent": [P, I] + [P] * 15,
+    "s2g_lstm2_bwd2": [P, I, I] + [P] * 17,
+    "s2g_pack_critic": [P] * 9 + [I, P],
+    "s2g_critic_batch_desc": [P, P, I, I, I, I, P, P],
+    "s2g_head_fwd": [P, P, P, P, I, I, P],
+    "s2g_head_bwd_dh": [P, P, P, I, I, P],
+    "s2g_head_bwd_w": [P, P, P, P, I, I, I, P],
+    "s2g_critic_loss": [P, P, I, F, F, F, F, P, P, P],
+    "s2g_generator_loss": [P, P, I, F, F, F, F, P, P, P],
+    "s2g_one_hot": [P, P, I, P, L, I, P],
+    "s2g_gp_interp": [P, P, P, P, I, I, I, I, P, P],
+    "s2g_gp_norm_penalty": [P, I, L, F, F, P, P, I, P],
+    "s2g_gp_scale": [P, P, P, F, L, P, I, P],
+    "s2g_embed_mul": [P, P, P, P, I, I, P],
+    "s2g_embed_mul_bwd": [P, P, P, P, I, I, I, P],
+    "s2g_lrelu_bwd": [P, P, L, P],
+    "s2g_bn_stats": [P, P, I, I, P],
+    "s2g_bn_lrelu_apply": [P, P, F, P, P, P, P, F, F, I, P, P, P, I, I, P],
+    "s2g_bn_lrelu_bwd_stats": [P, P, P, P, I, I, P],
+    "s2g_bn_bwd_apply": [P, P, P, F, P, P, P, I, I, P],
+    "s2g_adam": [P, P, P, P, L, F, F, F, F, I, F, P],
+}
+
+
+class S2GError(RuntimeError):
+    pass
+
+
+def load(path: str = LIB_PATH) -> ctypes.CDLL:
+    if not os.path.exists(path):
+        raise S2GError(f"{path} not found: build it with `make -C sequence-to-graph-gan_amd/csrc` "
+                       "(python -c 'import __graft_entry__ as g; g.build()'); there is no fallback path")
+    lib = ctypes.CDLL(path)
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise S2GError(f"libs2g.so does not export {name}") from e
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    return lib
+
+
+_LIB = None
+
+
+def get() -> ctypes.CDLL:
+    global _LIB
+    if _LIB is None:
+        _LIB = load()
+    return _LIB
+
+
+def call(name: str, *args) -> None:
+    rc = getattr(get(), name)(*args)
+    if rc != 0:
+        raise S2GError(f"{name} failed with code {rc}")

@@ -1,0 +1,171 @@
+"""Tensor-level wrappers over the C ABI: each function checks its operands on the host
+(device, dtype, contiguity, sizes the kernel's grid assumes) and enqueues one kernel on the
+current HIP stream.  torch is used only for device memory and the stream handle."""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import lib
+from .lib import S2GError, S2GGemm, call
+
+H = 50
+G4 = 200
+MASKW = 52
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: torch.Tensor, dtype=torch.float32, name="tensor"):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise S2GError(f"{name}: expected a CUDA/HIP tensor (this implementation has no CPU path)")
+    if t.dtype != dtype:
+        raise S2GError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise S2GError(f"{name}: expected a contiguous tensor")
+    return t
+
+
+def ptr(t: Optional[torch.Tensor], off_elems: int = 0) -> Optional[int]:
+    if t is None:
+        return None
+    return t.data_ptr() + off_elems * t.element_size()
+
+
+# ----------------------------------------------------------------------------- GEMM
+def gemm_raw(A: int, sam: int, sak: int, B: int, sbk: int, sbn: int, C: int, ldc: int, M: int, N: int, K: int,
+             bias: Optional[int] = None, alpha: float = 1.0, accumulate: bool = False, act: int = 0,
+             nsplit: int = 1, slab: int = 0, segT: int = 0, a_seg: int = 0, b_seg: int = 0, shift: bool = False,
+             kchunk: int = 0) -> None:
+    g = S2GGemm(A, sam, sak, B, sbk, sbn, C, ldc, slab, bias, M, N, K, kchunk, segT, a_seg, b_seg, int(shift),
+                int(accumulate), act, alpha)
+    call("s2g_gemm_f32", ctypes.byref(g), nsplit, stream_ptr())
+
+
+def pick_split(M: int, N: int, K: int, target_blocks: int = 768) -> int:
+    tiles = ((M + 63) // 64) * ((N + 63) // 64)
+    ns = max(1, min(target_blocks // max(tiles, 1), (K + 127) // 128))
+    return ns
+
+
+def reduce_slabs(slabs: torch.Tensor, slab: int, nslab: int, rows: int, cols: int, out: torch.Tensor,
+                 permute_rows: bool = False, accumulate: bool = False, scale: float = 1.0) -> None:
+    if out.numel() < rows * cols:
+        raise S2GError("reduce_slabs: output too small")
+    call("s2g_reduce_slabs", ptr(slabs), slab, nslab, rows, cols, ptr(out), int(permute_rows), int(accumulate),
+         scale, stream_ptr())
+
+
+class Scratch:
+    """Grow-only fp32 scratch buffer for split-K slabs (device memory only; no compute)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.buf = torch.empty(0, dtype=torch.float32, device=device)
+
+    def get(self, n: int) -> torch.Tensor:
+        if self.buf.numel() < n:
+            self.buf = torch.empty(int(n * 1.25) + 1024, dtype=torch.float32, device=self.device)
+        return self.buf
+
+
+def linear_fwd(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], y: torch.Tensor, act: int = 0) -> None:
+    """y[M,N] = act(x[M,K] @ W[N,K]^T + b)   (nn.Linear forward)"""
+    M, K = x.shape
+    N = W.shape[0]
+    _chk(x, name="x"); _chk(W, name="W"); _chk(y, name="y")
+    if W.shape[1] != K or tuple(y.shape) != (M, N):
+        raise S2GError("linear_fwd: shape mismatch")
+    gemm_raw(ptr(x), K, 1, ptr(W), 1, K, ptr(y), N, M, N, K, bias=ptr(b), act=act)
+
+
+def linear_bwd_dx(dy: torch.Tensor, W: torch.Tensor, dx: torch.Tensor, scratch: Scratch) -> None:
+    """dx[M,K] = dy[M,N] @ W[N,K]"""
+    M, N = dy.shape
+    K = W.shape[1]
+    _chk(dy, name="dy"); _chk(W, name="W"); _chk(dx, name="dx")
+    ns = pick_split(M, K, N)
+    if ns == 1:
+        gemm_raw(ptr(dy), N, 1, ptr(W), K, 1, ptr(dx), K, M, K, N)
+    else:
+        slabs = scratch.get(ns * M * K)
+        gemm_raw(ptr(dy), N, 1, ptr(W), K, 1, ptr(slabs), K, M, K, N, nsplit=ns, slab=M * K)
+        reduce_slabs(slabs, M * K, ns, M, K, dx)
+
+
+def linear_bwd_dw(dy: torch.Tensor, x: torch.Tensor, dW: torch.Tensor, scratch: Scratch,
+                  accumulate: bool = False) -> None:
+    """dW[N,K] (+)= dy[M,N]^T @ x[M,K]"""
+    M, N = dy.shape
+    K = x.shape[1]
+    _chk(dy, name="dy"); _chk(x, name="x"); _chk(dW, name="dW")
+    ns = pick_split(N, K, M)
+    if ns == 1:
+        gemm_raw(ptr(dy), 1, N, ptr(x), K, 1, ptr(dW), K, N, K, M, accumulate=accumulate)
+    else:
+        slabs = scratch.get(ns * N * K)
+        gemm_raw(ptr(dy), 1, N, ptr(x), K, 1, ptr(slabs), K, N, K, M, nsplit=ns, slab=N * K)
+        reduce_slabs(slabs, N * K, ns, N, K, dW, accumulate=accumulate)
+
+
+def colsum(X: torch.Tensor, rows: int, cols: int, ld: int, out: torch.Tensor, scratch: Scratch,
+           permute_rows: bool = False, accumulate: bool = False, row0: int = 0) -> None:
+    """out[c] (+)= sum_r X[row0 + r][c]"""
+    rpc = max(64, (rows + 255) // 256)
+    nch = (rows + rpc - 1) // rpc
+    part = scratch.get(nch * cols)
+    call("s2g_colsum", ptr(X, row0 * ld), ld, rows, cols, ptr(part), rpc, stream_ptr())
+    if permute_rows:
+        reduce_slabs(part, cols, nch, cols, 1, out, permute_rows=True, accumulate=accumulate)
+    else:
+        reduce_slabs(part, cols, nch, 1, cols, out, accumulate=accumulate)
+
+
+# ----------------------------------------------------------------------------- sampler
+MODES = {"gumbel_softmax": 0, "relaxed_bernoulli": 1}
+
+
+def gumbel_softmax_fwd(logits: torch.Tensor, U: Optional[torch.Tensor], tau: float, mode: int, hard: bool,
+                       bias: Optional[torch.Tensor] = None, bias_rows: int = 0):
+    _chk(logits, name="logits")
+    V = logits.shape[-1]
+    rows = logits.numel() // V
+    if U is not None:
+        _chk(U, name="U")
+        if U.numel() != logits.numel():
+            raise S2GError("gumbel_softmax: U must have the shape of logits")
+    y = torch.empty_like(logits)
+    y_soft = torch.empty_like(logits) if hard else None
+    call("s2g_gumbel_softmax_fwd", ptr(logits), ptr(U), ptr(bias), bias_rows, ptr(y), ptr(y_soft), rows, V,
+         float(tau), mode, int(hard), stream_ptr())
+    return y, (y_soft if hard else y)
+
+
+def gumbel_softmax_bwd(y_soft: torch.Tensor, dy: torch.Tensor, scale: float) -> torch.Tensor:
+    _chk(y_soft, name="y"); _chk(dy, name="dy")
+    V = y_soft.shape[-1]
+    dl = torch.empty_like(y_soft)
+    call("s2g_gumbel_softmax_bwd", ptr(y_soft), ptr(dy), ptr(dl), y_soft.numel() // V, V, float(scale), stream_ptr())
+    return dl
+
+
+def argmax_rows(y: torch.Tensor) -> torch.Tensor:
+    _chk(y, name="y")
+    V = y.shape[-1]
+    tok = torch.empty(y.shape[:-1], dtype=torch.int64, device=y.device)
+    call("s2g_argmax_rows", ptr(y), ptr(tok), y.numel() // V, V, stream_ptr())
+    return tok
+
+
+# ----------------------------------------------------------------------------- optimiser
+def adam(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, lr: float, b1: float, b2: float,
+         eps: float, step: int, gscale: float = 1.0) -> None:
+    for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _chk(t, name=n)
+        if t.numel() != p.numel():
+            raise S2GError("adam: size mismatch")
+    call("s2g_adam", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, b1, b2, eps, step, gscale, stream_ptr())
