@@ -202,7 +202,8 @@ extern "C" __global__ __launch_bounds__(1024) void s2g_k_gp_norm_penalty(float* 
   const int b = blockIdx.x;
   float* gb = g + (long)b * per_sample;
   float s = 0.0f;
-  const long n4 = per_sample >> 2;
+  // 16-byte accesses only when every sample starts 16-byte aligned
+  const long n4 = (per_sample & 3) == 0 ? (per_sample >> 2) : 0;
   for (long i = threadIdx.x; i < n4; i += blockDim.x) {
     float4 v = reinterpret_cast<const float4*>(gb)[i];
     s = fmaf(v.x, v.x, s); s = fmaf(v.y, v.y, s); s = fmaf(v.z, v.z, s); s = fmaf(v.w, v.w, s);

@@ -179,7 +179,7 @@ int s2g_gp_interp(const int* tokens, const int* lengths, const float* fake, cons
 int s2g_gp_norm_penalty(float* g, int B, long per_sample, float upstream, float n_batch, float* pen, float* norms,
                         int scale_in_place, void* stream) {
   if (!g || !pen || B <= 0 || per_sample <= 0 || !(n_batch > 0.0f)) return -1;
-  if ((per_sample * sizeof(float)) % 16 != 0) return -1;   // float4 rows
+  if (((uintptr_t)g) & 15) return -1;
   hipLaunchKernelGGL(s2g_k_gp_norm_penalty, dim3(B), dim3(1024), 0, ST(stream), g, per_sample, upstream, n_batch,
                      pen, norms, scale_in_place);
   return LAUNCH_OK();

@@ -95,6 +95,20 @@ class CriticEngine:
         self.ws, self._ws_key = ws, key
         return ws
 
+    def workspace_g(self, B: int, Tf: int) -> Dict[str, torch.Tensor]:
+        """Buffers of the generator-side D(fake) pass (first-order only)."""
+        key = (B, Tf)
+        if getattr(self, "_wsg_key", None) == key:
+            return self.wsg
+        dev = self.device
+        rows = B * Tf
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)  # noqa: E731
+        self.wsg = dict(gates0=z(rows, G4), cell0=z(rows, G4), gates1=z(rows, G4), cell1=z(rows, G4),
+                        delta0=z(rows, G4), delta1=z(rows, G4), hT=z(B, H), dhT=z(B, H), out=z(B, 3),
+                        dout=z(B, 3), losses=z(4), Pf=z(rows, G4), dfake=z(rows, self.V))
+        self._wsg_key = key
+        return self.wsg
+
     # ------------------------------------------------------------------ sweeps
     def _w(self):
         p = self.params.views
@@ -155,3 +169,144 @@ def make_desc(entries, device) -> torch.Tensor:
         arr[i, 4:6] = np.array([e.get("ca", 0.0), e.get("cp", 0.0)], dtype=np.float32).view(np.int32)
         arr[i, 6] = e.get("mask_off", -1); arr[i, 7] = e["ws_row"]
     return torch.from_numpy(arr).to(device)
+
+
+# ---------------------------------------------------------------------------------------------
+# Weight gradients: every dW is sum over rows of (gate gradient row)^T (operand row), a TN GEMM
+# over the saved buffers; several such products land in consecutive split-K slabs and one reduce
+# writes the torch-layout gradient.
+# ---------------------------------------------------------------------------------------------
+def _wgrad(eng: "CriticEngine", out: torch.Tensor, N: int, terms) -> None:
+    """terms: (A_ptr, K, B_ptr, sbk, sbn, segT, a_seg, b_seg, shift); A is [rows,200] row-major."""
+    slab = G4 * N
+    plan = []
+    total = 0
+    for t in terms:
+        K = t[1]
+        if K <= 0:
+            continue
+        ns = max(1, min(64, K // 512))
+        plan.append((t, ns, total))
+        total += ns
+    slabs = eng.scratch.get(total * slab)
+    for (A, K, B, sbk, sbn, segT, a_seg, b_seg, shift), ns, s0 in plan:
+        ops.gemm_raw(A, 1, G4, B, sbk, sbn, ptr(slabs, s0 * slab), N, G4, N, K, nsplit=ns, slab=slab, segT=segT,
+                     a_seg=a_seg, b_seg=b_seg, shift=shift)
+    ops.reduce_slabs(slabs, slab, total, G4, N, out, permute_rows=True)
+
+
+def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Tensor, labels: torch.Tensor,
+                     fake: torch.Tensor, alpha: torch.Tensor, lambda_gp: float, n_global: int, inv_wsum: float,
+                     mask: Optional[torch.Tensor] = None, class_w=(1.0, 2.0)):
+    """One critic loss + gradient evaluation (wgan_gp.py:297-317) on the batch
+    [real B | fake B | interp B], all three passes sharing each of the four sweeps.
+
+    tokens int32 [B,T] (zero padded), lengths int32 [B], labels int64 [B], fake fp32 [B,Tf,V],
+    alpha fp32 [B] (the draw of wgan_gp.py:228), mask fp32 [3*B*Tw, 52] or None.
+    n_global: global batch size (means and the penalty's 1/B use it; ranks then SUM gradients).
+    Fills eng.grads; returns (losses[3] = (-mean D(real), mean D(fake), class loss), pen[B])."""
+    B, T = tokens.shape
+    Tf, V = fake.shape[1], fake.shape[2]
+    if V != eng.V:
+        raise S2GError("critic_iteration: vocab mismatch")
+    for t, dt, nm in ((tokens, torch.int32, "tokens"), (lengths, torch.int32, "lengths"),
+                      (labels, torch.int64, "labels"), (fake, torch.float32, "fake"), (alpha, torch.float32, "alpha")):
+        ops._chk(t, dt, nm)
+    if alpha.numel() != B or lengths.numel() != B or labels.numel() != B or fake.shape[0] != B:
+        raise S2GError("critic_iteration: batch size mismatch")
+    Tw = max(T, Tf)
+    ws = eng.workspace(3 * B, Tw, B)
+    if mask is not None:
+        ops._chk(mask, name="mask")
+        if tuple(mask.shape) != (3 * B * Tw, MASKW):
+            raise S2GError("critic_iteration: mask must be [3*B*Tw, 52]")
+    p, g, st = eng.params.views, eng.grads.views, stream_ptr()
+    desc = ws["desc"]
+    dptr = ptr(desc)
+    call("s2g_critic_batch_desc", ptr(lengths), ptr(alpha), B, T, Tf, int(mask is not None), dptr, st)
+    if "Pf" not in ws or ws["Pf"].shape[0] != B * Tf:
+        ws["Pf"] = torch.empty(B * Tf, G4, device=eng.device)
+        ws["xreal"] = torch.empty(B * T, V, device=eng.device)
+        ws["xhat"] = torch.empty(B * T, V, device=eng.device)
+    # sweep A on 3B sequences
+    eng.project(fake, ws["Pf"])
+    eng.sweep_fwd(ws, dptr, 3 * B, Tw, tokens, ws["Pf"], mask)
+    eng.head_fwd(ws, 3 * B)
+    inv_n = 1.0 / float(n_global)
+    call("s2g_critic_loss", ptr(ws["out"]), ptr(labels), B, inv_n, inv_wsum, class_w[0], class_w[1],
+         ptr(ws["dout"]), ptr(ws["losses"]), st)
+    call("s2g_head_bwd_dh", ptr(ws["dout"]), ptr(p["fc.weight"]), ptr(ws["dhT"]), 3 * B, 3, st)
+    call("s2g_head_bwd_w", ptr(ws["dout"]), ptr(ws["hT"]), ptr(g["fc.weight"]), ptr(g["fc.bias"]), 2 * B, 3, 0, st)
+    # sweep B on 3B sequences (the interp third with d(out) = e0 and stored adjoints)
+    eng.sweep_bwd(ws, dptr, 3 * B, Tw, mask, adj_seq0=2 * B)
+    # input gradient of the interp third, its norm, the penalty and the direction v (in place)
+    r_int = 2 * B * Tw
+    ops.gemm_raw(ptr(ws["delta0"], r_int * G4), G4, 1, ptr(eng.W0p), V, 1, ptr(ws["G"]), V, B * Tw, V, G4)
+    call("s2g_gp_norm_penalty", ptr(ws["G"]), B, Tw * V, float(lambda_gp), float(n_global), ptr(ws["pen"]),
+         ptr(ws["norms"]), 1, st)
+    eng.project(ws["G"], ws["Pv"])
+    # sweeps C and D on the interp third (group-relative descriptors = 4th block of desc)
+    drel = ptr(desc, 3 * B * 8)
+    mrel = ptr(mask, r_int * MASKW) if mask is not None else None
+    eng.sweep_tangent(ws, drel, B, mrel, r_int)
+    eng.sweep_bwd2(ws, drel, B, Tw, mrel, r_int)
+    # operands of the weight-gradient products
+    call("s2g_one_hot", ptr(tokens), ptr(lengths), T, ptr(ws["xreal"]), B * T, V, st)
+    call("s2g_gp_interp", ptr(tokens), ptr(lengths), ptr(fake), ptr(alpha), B, T, Tf, V, ptr(ws["xhat"]), st)
+    d0, d1, c0, c1 = ws["delta0"], ws["delta1"], ws["cell0"], ws["cell1"]
+    a0, a1, cd0, cd1 = ws["abar0"], ws["abar1"], ws["celld0"], ws["celld1"]
+    oi = r_int * G4
+    n12, n3 = 2 * B * Tw, B * Tw
+    _wgrad(eng, g["lstm.weight_ih_l0"], V, [
+        (ptr(d0), B * T, ptr(ws["xreal"]), V, 1, T, Tw, T, False),
+        (ptr(d0, B * Tw * G4), B * Tf, ptr(fake), V, 1, Tf, Tw, Tf, False),
+        (ptr(a0), B * T, ptr(ws["xhat"]), V, 1, T, Tw, T, False),
+        (ptr(d0, oi), n3, ptr(ws["G"]), V, 1, 0, 0, 0, False)])
+    _wgrad(eng, g["lstm.weight_hh_l0"], H, [
+        (ptr(d0), n12, ptr(c0, 2), G4, 4, Tw, Tw, Tw, True),
+        (ptr(a0), n3, ptr(c0, oi + 2), G4, 4, Tw, Tw, Tw, True),
+        (ptr(d0, oi), n3, ptr(cd0, 1), G4, 4, Tw, Tw, Tw, True)])
+    _wgrad(eng, g["lstm.weight_ih_l1"], H, [
+        (ptr(d1), n12, ptr(c0, 3), G4, 4, 0, 0, 0, False),
+        (ptr(a1), n3, ptr(c0, oi + 3), G4, 4, 0, 0, 0, False),
+        (ptr(d1, oi), n3, ptr(cd0, 2), G4, 4, 0, 0, 0, False)])
+    _wgrad(eng, g["lstm.weight_hh_l1"], H, [
+        (ptr(d1), n12, ptr(c1, 2), G4, 4, Tw, Tw, Tw, True),
+        (ptr(a1), n3, ptr(c1, oi + 2), G4, 4, Tw, Tw, Tw, True),
+        (ptr(d1, oi), n3, ptr(cd1, 1), G4, 4, Tw, Tw, Tw, True)])
+    sc = eng.scratch
+    ops.colsum(d0, n12, G4, G4, g["lstm.bias_ih_l0"], sc, permute_rows=True)
+    ops.colsum(a0, n3, G4, G4, g["lstm.bias_ih_l0"], sc, permute_rows=True, accumulate=True)
+    ops.colsum(d1, n12, G4, G4, g["lstm.bias_ih_l1"], sc, permute_rows=True)
+    ops.colsum(a1, n3, G4, G4, g["lstm.bias_ih_l1"], sc, permute_rows=True, accumulate=True)
+    g["lstm.bias_hh_l0"].copy_(g["lstm.bias_ih_l0"])
+    g["lstm.bias_hh_l1"].copy_(g["lstm.bias_ih_l1"])
+    # second-order part of fc.weight[0]: sum_b hdot1_final(b)
+    ops.colsum(ws["hdotT"], B, H, H, g["fc.weight"][0], sc, accumulate=True)
+    return ws["losses"], ws["pen"]
+
+
+def critic_forward_backward_fake(eng: CriticEngine, fake: torch.Tensor, labels: torch.Tensor, n_global: int,
+                                 inv_wsum: float, mask: Optional[torch.Tensor] = None, class_w=(1.0, 2.0)):
+    """Generator-side pass (wgan_gp.py:333-342): D(fake) dense, generator loss, and d loss/d fake.
+    The critic's own parameter gradients of this pass are discarded by the reference
+    (optimizer_D.zero_grad at the next iteration, wgan_gp.py:288) and are not computed.
+    Returns (losses[2] = (-mean validity, 0.25*CE), dfake [B,Tf,V])."""
+    B, Tf, V = fake.shape
+    ops._chk(fake, name="fake"); ops._chk(labels, torch.int64, "labels")
+    ws = eng.workspace_g(B, Tf)
+    st = stream_ptr()
+    p = eng.params.views
+    desc = make_desc([dict(len=Tf, p_off=b * Tf, p_len=Tf, ca=0.0, cp=1.0, ws_row=b * Tf,
+                           mask_off=(b * Tf if mask is not None else -1)) for b in range(B)], eng.device) \
+        if ws.get("desc_key") != (B, Tf, mask is not None) else ws["desc"]
+    ws["desc"], ws["desc_key"] = desc, (B, Tf, mask is not None)
+    eng.project(fake, ws["Pf"])
+    eng.sweep_fwd(ws, ptr(desc), B, Tf, None, ws["Pf"], mask)
+    eng.head_fwd(ws, B)
+    call("s2g_generator_loss", ptr(ws["out"]), ptr(labels), B, 1.0 / float(n_global), inv_wsum, class_w[0],
+         class_w[1], ptr(ws["dout"]), ptr(ws["losses"]), st)
+    call("s2g_head_bwd_dh", ptr(ws["dout"]), ptr(p["fc.weight"]), ptr(ws["dhT"]), B, 3, st)
+    eng.sweep_bwd(ws, ptr(desc), B, Tf, mask)
+    ops.gemm_raw(ptr(ws["delta0"]), G4, 1, ptr(eng.W0p), V, 1, ptr(ws["dfake"]), V, B * Tf, V, G4)
+    return ws["losses"], ws["dfake"].view(B, Tf, V)

@@ -1,0 +1,154 @@
+"""Host orchestration of the generator (reference: Generator, wgan_gp.py:141-171): label
+embedding product -> Linear+LeakyReLU -> 2 x (Linear, BatchNorm1d(eps=0.8), LeakyReLU) ->
+Linear(512, V*seq_len) -> Gumbel-softmax.  Forward and hand-derived backward, every product an
+fp32 MFMA GEMM of libs2g; parameters live in one flat buffer (one fused Adam launch, one
+all-reduce bucket)."""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+from .critic import FlatBuffer
+from .lib import S2GError, call
+from .ops import ptr, stream_ptr
+
+LATENT = 100
+BN_EPS = 0.8          # nn.BatchNorm1d(out_feat, 0.8): the second positional argument is eps
+BN_MOMENTUM = 0.1
+
+
+def generator_shapes(vocab: int, seq_len: int, n_classes: int = 2):
+    """state_dict order of the reference Generator (parameters only)."""
+    return [("model.0.weight", (128, LATENT)), ("model.0.bias", (128,)),
+            ("model.2.weight", (256, 128)), ("model.2.bias", (256,)),
+            ("model.3.weight", (256,)), ("model.3.bias", (256,)),
+            ("model.5.weight", (512, 256)), ("model.5.bias", (512,)),
+            ("model.6.weight", (512,)), ("model.6.bias", (512,)),
+            ("model.8.weight", (vocab * seq_len, 512)), ("model.8.bias", (vocab * seq_len,)),
+            ("label_embedding.weight", (n_classes, LATENT))]
+
+
+class NoComm:
+    world = 1
+
+    def allreduce(self, t: torch.Tensor) -> None:  # sum over ranks, in place
+        return
+
+
+class GeneratorEngine:
+    def __init__(self, vocab: int, seq_len: int, device, n_classes: int = 2, comm=None):
+        self.V, self.L, self.n_classes = vocab, seq_len, n_classes
+        self.device = device
+        self.comm = comm or NoComm()
+        self.params = FlatBuffer(generator_shapes(vocab, seq_len, n_classes), device)
+        self.grads = self.params.like()
+        z = lambda n: torch.zeros(n, dtype=torch.float32, device=device)  # noqa: E731
+        self.buffers = {"model.3.running_mean": z(256), "model.3.running_var": torch.ones(256, device=device),
+                        "model.6.running_mean": z(512), "model.6.running_var": torch.ones(512, device=device)}
+        self.num_batches_tracked = 0
+        self.scratch = ops.Scratch(device)
+        self.saved: Dict[str, torch.Tensor] = {}
+
+    def load(self, state: Dict[str, torch.Tensor]) -> None:
+        for k, v in self.params.views.items():
+            v.copy_(state[k].to(self.device, torch.float32))
+        for k in self.buffers:
+            if k in state:
+                self.buffers[k].copy_(state[k].to(self.device, torch.float32))
+
+    # ------------------------------------------------------------------ forward
+    def _bn(self, pre, name, training, update_running, B, F_):
+        p = self.params.views
+        y = torch.empty_like(pre)
+        xhat = torch.empty_like(pre) if training else None
+        invstd = torch.empty(F_, device=self.device) if training else None
+        stats = None
+        n_global = float(B * self.comm.world)
+        if training:
+            stats = torch.empty(2 * F_, device=self.device)
+            call("s2g_bn_stats", ptr(pre), ptr(stats), B, F_, stream_ptr())
+            self.comm.allreduce(stats)
+        call("s2g_bn_lrelu_apply", ptr(pre), ptr(stats), n_global, ptr(p[name + ".weight"]), ptr(p[name + ".bias"]),
+             ptr(self.buffers[name + ".running_mean"]), ptr(self.buffers[name + ".running_var"]), BN_EPS,
+             BN_MOMENTUM, int(training and update_running), ptr(y), ptr(xhat), ptr(invstd), B, F_, stream_ptr())
+        return y, xhat, invstd
+
+    def forward(self, z: torch.Tensor, labels: torch.Tensor, U: Optional[torch.Tensor], tau: float, hard: bool,
+                training: bool = True, save: bool = True, act: str = "gumbel_softmax") -> torch.Tensor:
+        ops._chk(z, name="noise")
+        ops._chk(labels, torch.int64, "labels")
+        B = z.shape[0]
+        if z.shape[1] != LATENT or labels.shape[0] != B:
+            raise S2GError("generator: noise must be [B,100] and labels [B]")
+        p = self.params.views
+        dev = self.device
+        x0 = torch.empty(B, LATENT, device=dev)
+        call("s2g_embed_mul", ptr(z), ptr(labels), ptr(p["label_embedding.weight"]), ptr(x0), B, LATENT,
+             stream_ptr())
+        a1 = torch.empty(B, 128, device=dev)
+        ops.linear_fwd(x0, p["model.0.weight"], p["model.0.bias"], a1, act=1)
+        pre2 = torch.empty(B, 256, device=dev)
+        ops.linear_fwd(a1, p["model.2.weight"], p["model.2.bias"], pre2)
+        a2, xhat2, inv2 = self._bn(pre2, "model.3", training, True, B, 256)
+        pre3 = torch.empty(B, 512, device=dev)
+        ops.linear_fwd(a2, p["model.5.weight"], p["model.5.bias"], pre3)
+        a3, xhat3, inv3 = self._bn(pre3, "model.6", training, True, B, 512)
+        if training:
+            self.num_batches_tracked += 1
+        logits = torch.empty(B, self.L * self.V, device=dev)
+        ops.linear_fwd(a3, p["model.8.weight"], p["model.8.bias"], logits)
+        mode = ops.MODES.get(act, 2)
+        if mode == 0 and U is None:
+            U = torch.rand(B, self.L, self.V, device=dev)      # noise draw only; the sampler is the kernel
+        y, y_soft = ops.gumbel_softmax_fwd(logits.view(B, self.L, self.V), U if mode == 0 else None, tau, mode,
+                                           hard)
+        if save:
+            self.saved = dict(z=z, labels=labels, x0=x0, a1=a1, a2=a2, xhat2=xhat2, inv2=inv2, a3=a3, xhat3=xhat3,
+                              inv3=inv3, y_soft=y_soft, scale=(1.0 if mode == 2 else 1.0 / tau), B=B)
+        return y
+
+    # ------------------------------------------------------------------ backward
+    def _bn_bwd(self, a, da, xhat, inv, name, B, F_):
+        g = self.grads.views
+        sums = torch.empty(2 * F_, device=self.device)
+        call("s2g_bn_lrelu_bwd_stats", ptr(a), ptr(da), ptr(xhat), ptr(sums), B, F_, stream_ptr())
+        self.comm.allreduce(sums)
+        g[name + ".bias"].copy_(sums[:F_])
+        g[name + ".weight"].copy_(sums[F_:])
+        dpre = torch.empty_like(da)
+        call("s2g_bn_bwd_apply", ptr(da), ptr(xhat), ptr(sums), float(B * self.comm.world),
+             ptr(self.params.views[name + ".weight"]), ptr(inv), ptr(dpre), B, F_, stream_ptr())
+        return dpre
+
+    def backward(self, dy: torch.Tensor) -> None:
+        """Fills self.grads (local sums; BN gamma/beta gradients are already global) from d loss/d y."""
+        s = self.saved
+        if not s:
+            raise S2GError("generator.backward called without a saved forward")
+        B = s["B"]
+        p, g, sc, dev = self.params.views, self.grads.views, self.scratch, self.device
+        dlogits = ops.gumbel_softmax_bwd(s["y_soft"], dy.contiguous().view_as(s["y_soft"]), s["scale"])
+        dl2 = dlogits.view(B, self.L * self.V)
+        ops.linear_bwd_dw(dl2, s["a3"], g["model.8.weight"], sc)
+        ops.colsum(dl2, B, self.L * self.V, self.L * self.V, g["model.8.bias"], sc)
+        da3 = torch.empty(B, 512, device=dev)
+        ops.linear_bwd_dx(dl2, p["model.8.weight"], da3, sc)
+        dpre3 = self._bn_bwd(s["a3"], da3, s["xhat3"], s["inv3"], "model.6", B, 512)
+        ops.linear_bwd_dw(dpre3, s["a2"], g["model.5.weight"], sc)
+        ops.colsum(dpre3, B, 512, 512, g["model.5.bias"], sc)
+        da2 = torch.empty(B, 256, device=dev)
+        ops.linear_bwd_dx(dpre3, p["model.5.weight"], da2, sc)
+        dpre2 = self._bn_bwd(s["a2"], da2, s["xhat2"], s["inv2"], "model.3", B, 256)
+        ops.linear_bwd_dw(dpre2, s["a1"], g["model.2.weight"], sc)
+        ops.colsum(dpre2, B, 256, 256, g["model.2.bias"], sc)
+        da1 = torch.empty(B, 128, device=dev)
+        ops.linear_bwd_dx(dpre2, p["model.2.weight"], da1, sc)
+        call("s2g_lrelu_bwd", ptr(s["a1"]), ptr(da1), da1.numel(), stream_ptr())
+        ops.linear_bwd_dw(da1, s["x0"], g["model.0.weight"], sc)
+        ops.colsum(da1, B, 128, 128, g["model.0.bias"], sc)
+        dx0 = torch.empty(B, LATENT, device=dev)
+        ops.linear_bwd_dx(da1, p["model.0.weight"], dx0, sc)
+        call("s2g_embed_mul_bwd", ptr(s["z"]), ptr(s["labels"]), ptr(dx0), ptr(g["label_embedding.weight"]), B,
+             LATENT, self.n_classes, stream_ptr())

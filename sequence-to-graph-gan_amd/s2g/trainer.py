@@ -1,0 +1,128 @@
+"""The fused WGAN-GP step (reference: train_wgan's inner loop, wgan_gp.py:274-343): critic
+update on every batch, generator update when i % n_critic == 0 (after that batch's critic
+update, same z and labels, fresh Gumbel noise).  All arithmetic runs in libs2g kernels; this
+file only sequences launches, owns the Adam state and talks to the data-parallel communicator."""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+from .critic import CriticEngine, critic_forward_backward_fake, critic_iteration
+from .generator import LATENT, GeneratorEngine, NoComm
+from .lib import S2GError
+from .ops import MASKW, H
+
+CLASS_W = (1.0, 2.0)      # wgan_gp.py:267
+
+
+def class_weight_sum(labels_cpu: torch.Tensor) -> float:
+    """sum_b w[y_b], the denominator of the weighted CrossEntropyLoss mean (wgan_gp.py:267-268)."""
+    n1 = int((labels_cpu == 1).sum())
+    return CLASS_W[0] * (labels_cpu.numel() - n1) + CLASS_W[1] * n1
+
+
+def dropout_mask(rows: int, p: float, device) -> Optional[torch.Tensor]:
+    """[rows, 52] multiplier (0 or 1/(1-p)) for the layer-0 outputs, as nn.LSTM(dropout=p) applies
+    in train mode (wgan_gp.py:189); columns 50,51 are padding."""
+    if p <= 0.0:
+        return None
+    m = (torch.rand(rows, MASKW, device=device) >= p).to(torch.float32) / (1.0 - p)
+    m[:, H:] = 0.0
+    return m
+
+
+class WGANGPTrainer:
+    def __init__(self, vocab: int, gen_seq_len: int, device, lr: float = 2e-4, b1: float = 0.5, b2: float = 0.999,
+                 lambda_gp: float = 10.0, tau: float = 0.5, hard: bool = False, n_critic: int = 5,
+                 drop_rate: float = 0.3, comm=None):
+        self.device = torch.device(device)
+        self.comm = comm or NoComm()
+        self.G = GeneratorEngine(vocab, gen_seq_len, self.device, comm=self.comm)
+        self.D = CriticEngine(vocab, self.device)
+        self.lr, self.b1, self.b2, self.eps = lr, b1, b2, 1e-8
+        self.lambda_gp, self.tau, self.hard, self.n_critic, self.drop_rate = lambda_gp, tau, hard, n_critic, drop_rate
+        self.V, self.L = vocab, gen_seq_len
+        self.mD, self.vD = torch.zeros_like(self.D.params.flat), torch.zeros_like(self.D.params.flat)
+        self.mG, self.vG = torch.zeros_like(self.G.params.flat), torch.zeros_like(self.G.params.flat)
+        self.tD = 0
+        self.tG = 0
+        self.last: Dict[str, torch.Tensor] = {}
+
+    # ------------------------------------------------------------------ updates
+    def _adam(self, eng, m, v, step):
+        self.comm.allreduce(eng.grads.flat)
+        ops.adam(eng.params.flat, eng.grads.flat, m, v, self.lr, self.b1, self.b2, self.eps, step)
+
+    def critic_step(self, tokens: torch.Tensor, labels: torch.Tensor, lengths: torch.Tensor, wsum: float,
+                    z: Optional[torch.Tensor] = None, U: Optional[torch.Tensor] = None,
+                    alpha: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
+                    update: bool = True):
+        """tokens int32 [B,T], labels int64 [B], lengths int32 [B]: device tensors of this rank's shard.
+        wsum: global sum of class weights.  Noise defaults to fresh device draws.
+        Returns the loss parts (device tensors; nothing synchronises)."""
+        B, T = tokens.shape
+        dev = self.device
+        n_global = B * self.comm.world
+        if z is None:
+            z = torch.randn(B, LATENT, device=dev)
+        if alpha is None:
+            alpha = torch.rand(B, device=dev)
+        fake = self.G.forward(z, labels, U, self.tau, self.hard, training=True, save=False)   # .detach(): no graph
+        Tw = max(T, self.L)
+        if mask is None and self.drop_rate > 0.0:
+            mask = dropout_mask(3 * B * Tw, self.drop_rate, dev)
+        losses, pen = critic_iteration(self.D, tokens, lengths, labels, fake, alpha.reshape(-1).contiguous(),
+                                       self.lambda_gp, n_global, 1.0 / wsum, mask, CLASS_W)
+        if update:
+            self.tD += 1
+            self._adam(self.D, self.mD, self.vD, self.tD)
+            self.D.repack()
+        self.last = dict(z=z, labels=labels, d_parts=losses, pen=pen, n_global=n_global, wsum=wsum)
+        return losses, pen
+
+    def d_loss(self) -> torch.Tensor:
+        """d_loss of the last critic_step as a 0-dim device tensor (wgan_gp.py:313-315)."""
+        l, pen = self.last["d_parts"], self.last["pen"]
+        t = (l[0] + l[1] + l[2] + self.lambda_gp * pen.sum() / self.last["n_global"]).reshape(1).clone()
+        self.comm.allreduce(t)
+        return t[0]
+
+    def generator_step(self, labels: Optional[torch.Tensor] = None, z: Optional[torch.Tensor] = None,
+                       U: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
+                       wsum: Optional[float] = None, update: bool = True):
+        """wgan_gp.py:330-343 with the z / labels of the preceding critic_step by default."""
+        labels = self.last["labels"] if labels is None else labels
+        z = self.last["z"] if z is None else z
+        wsum = self.last["wsum"] if wsum is None else wsum
+        B = z.shape[0]
+        n_global = B * self.comm.world
+        fake = self.G.forward(z, labels, U, self.tau, self.hard, training=True, save=True)
+        if mask is None and self.drop_rate > 0.0:
+            mask = dropout_mask(B * self.L, self.drop_rate, self.device)
+        losses, dfake = critic_forward_backward_fake(self.D, fake, labels, n_global, 1.0 / wsum, mask, CLASS_W)
+        self.G.backward(dfake)
+        if update:
+            self.tG += 1
+            self._adam(self.G, self.mG, self.vG, self.tG)
+        self.last["g_parts"] = losses
+        return losses
+
+    def g_loss(self) -> torch.Tensor:
+        l = self.last["g_parts"]
+        t = (l[0] + l[1]).reshape(1).clone()
+        self.comm.allreduce(t)
+        return t[0]
+
+    # ------------------------------------------------------------------ the full step
+    def full_step(self, batches, noises=None):
+        """batches: n_critic device batches (tokens i32, labels i64, lengths i32, wsum).  Generator
+        update after the first batch's critic update (i % n_critic == 0, wgan_gp.py:323)."""
+        for i, (tokens, labels, lengths, wsum) in enumerate(batches):
+            nz = noises[i] if noises is not None else {}
+            self.critic_step(tokens, labels, lengths, wsum, nz.get("z"), nz.get("U"), nz.get("alpha"),
+                             nz.get("mask"))
+            if i % self.n_critic == 0:
+                self.generator_step(U=nz.get("U2"), mask=nz.get("mask_g"))

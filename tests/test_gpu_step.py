@@ -1,0 +1,161 @@
+"""The fused HIP step against (a) the CPU oracle on seeded inputs and (b) golden vectors produced
+by the reference itself (tests/golden/g2, g7, g8).  Tolerance 1e-3 relative: the fp32 bound the
+north star states; "atol" covers tensors that are mathematically zero."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import common
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+DEV = "cuda:0"
+
+
+def dev_batch(tokens, labels, lengths):
+    from s2g.trainer import class_weight_sum
+    return (tokens.to(torch.int32).to(DEV).contiguous(), labels.to(DEV), lengths.to(torch.int32).to(DEV),
+            class_weight_sum(labels))
+
+
+def pack_masks(masks, B, Tw):
+    """three [B,T_i,50] masks (real, fake, interp) -> [3*B*Tw, 52] workspace-row layout"""
+    out = torch.zeros(3 * B, Tw, 52)
+    for i, m in enumerate(masks):
+        out[i * B:(i + 1) * B, :m.shape[1], :50] = m
+    return out.view(3 * B * Tw, 52).to(DEV)
+
+
+@pytest.mark.parametrize("Tf,with_mask,hard", [(7, False, False), (20, True, False), (25, True, True)])
+def test_critic_iteration_matches_oracle(Tf, with_mask, hard):
+    from oracle import wgan_gp_cpu as O
+    from s2g.trainer import WGANGPTrainer
+    B, T, V = 6, 20, 175
+    pd = common.critic_params(51, scale=2.0)
+    pg = common.generator_params(52, V, Tf)
+    tokens, labels, lengths = common.batch(53, B, T, lengths=[20, 20, 14, 9, 3, 1])
+    nz = common.noise(54, B, Tf)
+    g = common.gen(55)
+    masks = (None, None, None)
+    if with_mask:
+        masks = tuple((torch.rand((B, t, 50), generator=g) > 0.3).float() / 0.7 for t in (T, Tf, T))
+    cfg = dict(vocab=V, tau=0.5, hard=hard, lambda_gp=10.0, n_critic=5, gen_seq_len=Tf)
+    bn = common.bn_buffers()
+    pd_o = {k: v.clone() for k, v in pd.items()}
+    opt = O.Adam(pd_o, 2e-4, 0.5, 0.999)
+    d_loss, fake_o, gd, parts = O.critic_iteration({k: v.clone() for k, v in pg.items()}, bn, pd_o, opt, tokens,
+                                                   labels, lengths, nz["z"], nz["U"], nz["alpha"], cfg, masks)
+
+    tr = WGANGPTrainer(V, Tf, DEV, hard=hard, drop_rate=0.0)
+    tr.G.load(pg); tr.D.load(pd)
+    tok, lab, ln, wsum = dev_batch(tokens, labels, lengths)
+    mk = pack_masks(masks, B, max(T, Tf)) if with_mask else None
+    tr.critic_step(tok, lab, ln, wsum, nz["z"].to(DEV), nz["U"].to(DEV), nz["alpha"].view(-1).to(DEV), mk)
+    torch.cuda.synchronize()
+    assert_close(tr.d_loss().cpu(), torch.tensor(d_loss), TOL, "d_loss")
+    assert_close(tr.last["pen"].cpu().mean(), parts["gp"], TOL, "gp")
+    for n, gref in gd.items():
+        assert_close(tr.D.grads.views[n].cpu(), gref, TOL, f"grad {n}", atol=1e-7)
+    for n in pd:
+        assert_close(tr.D.params.views[n].cpu(), pd_o[n], TOL, f"param {n}")
+    for b in ("model.3.running_mean", "model.3.running_var", "model.6.running_mean", "model.6.running_var"):
+        assert_close(tr.G.buffers[b].cpu(), bn[b], TOL, b)
+
+
+def test_generator_matches_reference_golden(golden):
+    from s2g.generator import GeneratorEngine
+    G = golden("g2_generator.pt")
+    for seq_len in (8, 120):
+        eng = GeneratorEngine(175, seq_len, torch.device(DEV))
+        eng.load(common.generator_params(202, 175, seq_len))
+        nz = common.noise(203, 6, seq_len)
+        labels = torch.tensor([0, 1, 1, 0, 1, 0], device=DEV)
+        y = eng.forward(nz["z"].to(DEV), labels, nz["U"].to(DEV), 0.5, False, training=True)
+        dy = torch.randn(y.shape, generator=common.gen(204)).to(DEV)
+        eng.backward(dy)
+        torch.cuda.synchronize()
+        tag = f"T{seq_len}"
+        assert_close((y if seq_len == 8 else y[:, :4]).cpu(), G[f"{tag}.y"], TOL, "y")
+        for n, gv in eng.grads.views.items():
+            if f"{tag}.grad.{n}" in G:
+                assert_close(gv.cpu(), G[f"{tag}.grad.{n}"], TOL, n, atol=1e-6)
+            else:
+                assert_close(gv.cpu().norm(), G[f"{tag}.grad_norm.{n}"], TOL, n)
+                assert_close(gv.cpu()[:64], G[f"{tag}.grad_head.{n}"], TOL, n)
+        for b in ("model.3.running_mean", "model.3.running_var", "model.6.running_mean", "model.6.running_var"):
+            assert_close(eng.buffers[b].cpu(), G[f"{tag}.{b}"], TOL, b)
+        # eval mode + hard sampling + argmax decode (generate_fake_data.py:61-66)
+        from s2g import ops
+        yh = eng.forward(nz["z"].to(DEV), labels, nz["U2"].to(DEV), 0.5, True, training=False, save=False)
+        tok = ops.argmax_rows(yh)
+        torch.cuda.synchronize()
+        assert (tok.cpu() == G[f"{tag}.eval_tokens"]).float().mean() > 0.999
+        assert torch.all(yh.sum(-1) == 1.0)
+
+
+@pytest.mark.parametrize("Tf", [4, 32])
+def test_full_steps_match_reference_golden(golden, Tf):
+    """6 batches through the trainer = what the reference's own train_wgan did for g7: generator
+    updates at i = 0 and i = 5; final critic/generator parameters and BN buffers must agree."""
+    from s2g.trainer import WGANGPTrainer
+    G = golden("g7_full_step.pt")
+    k = f"Tf{Tf}"
+    tr = WGANGPTrainer(175, Tf, DEV, drop_rate=0.0)
+    pg = common.generator_params(701, 175, Tf)
+    tr.G.load(pg); tr.D.load(common.critic_params(702, scale=1.5))
+    d_losses, g_losses = [], []
+    for i in range(6):
+        tok, lab, ln, wsum = dev_batch(*common.batch(710 + i, 8, 32, min_len=3))
+        nz = {n: v.to(DEV) for n, v in common.noise(720 + i, 8, Tf).items()}
+        tr.critic_step(tok, lab, ln, wsum, nz["z"], nz["U"], nz["alpha"].view(-1).contiguous())
+        d_losses.append(float(tr.d_loss()))
+        if i % 5 == 0:
+            tr.generator_step(U=nz["U2"])
+            g_losses.append(float(tr.g_loss()))
+    torch.cuda.synchronize()
+    printed = G[f"{k}.printed_losses"]
+    assert abs(d_losses[0] - float(printed[0, 0])) < TOL * max(1.0, abs(d_losses[0]))
+    assert abs(d_losses[5] - float(printed[1, 0])) < TOL * max(1.0, abs(d_losses[5]))
+    assert abs(g_losses[0] - float(printed[0, 1])) < TOL * max(1.0, abs(g_losses[0]))
+    assert abs(g_losses[1] - float(printed[1, 1])) < TOL * max(1.0, abs(g_losses[1]))
+    for n, v in tr.D.params.views.items():
+        assert_close(v.cpu(), G[f"{k}.D.{n}"], TOL, f"D {n}")
+    for n, v in tr.G.params.views.items():
+        if f"{k}.G.{n}" in G:
+            assert_close(v.cpu(), G[f"{k}.G.{n}"], TOL, f"G {n}", atol=1e-5)
+        else:
+            assert_close(v.cpu()[:32], G[f"{k}.G.head.{n}"], TOL, f"G {n}")
+            assert_close((v.cpu() - pg[n]).norm(), G[f"{k}.G.delta_norm.{n}"], 5e-3, f"G delta {n}")
+    for b in ("model.3.running_mean", "model.3.running_var", "model.6.running_mean", "model.6.running_var"):
+        assert_close(tr.G.buffers[b].cpu(), G[f"{k}.G.{b}"], TOL, b)
+
+
+@pytest.mark.parametrize("tag", ["fixed", "adfa"])
+def test_full_size_iteration_matches_reference_golden(golden, tag):
+    """North-star shape: B=64, L=512, V=175, generator seq_len 512.  One critic iteration and the
+    generator update against gradients recorded from the reference (g8)."""
+    from s2g.trainer import WGANGPTrainer
+    G = golden("g8_full_size.pt")
+    lengths = [512] * 64 if tag == "fixed" else common.adfa_lengths(805, 64).tolist()
+    tr = WGANGPTrainer(175, 512, DEV, drop_rate=0.0)
+    tr.G.load(common.generator_params(801, 175, 512)); tr.D.load(common.critic_params(802))
+    tok, lab, ln, wsum = dev_batch(*common.batch(810, 64, 512, lengths=lengths))
+    nz = {n: v.to(DEV) for n, v in common.noise(820, 64, 512).items()}
+    tr.critic_step(tok, lab, ln, wsum, nz["z"], nz["U"], nz["alpha"].view(-1).contiguous())
+    d_loss = float(tr.d_loss())
+    dgr = {n: v.cpu().clone() for n, v in tr.D.grads.views.items()}
+    tr.generator_step(U=nz["U2"])
+    g_loss = float(tr.g_loss())
+    torch.cuda.synchronize()
+    printed = G[f"{tag}.printed_losses"]
+    assert abs(d_loss - float(printed[0, 0])) < TOL * abs(d_loss)
+    assert abs(g_loss - float(printed[0, 1])) < TOL * max(1.0, abs(g_loss))
+    for n, v in dgr.items():
+        assert_close(v, G[f"{tag}.D.grad.{n}"], 2e-3, f"D grad {n}", atol=1e-7)
+    for n, v in tr.G.grads.views.items():
+        if f"{tag}.G.grad.{n}" in G:
+            assert_close(v.cpu(), G[f"{tag}.G.grad.{n}"], 2e-3, f"G grad {n}", atol=1e-7)
+        else:
+            assert_close(v.cpu().norm(), G[f"{tag}.G.grad_norm.{n}"], 2e-3, f"G grad norm {n}")
+            assert_close(v.cpu().reshape(-1)[:4096], G[f"{tag}.G.grad_head.{n}"], 2e-3, f"G grad head {n}")
