@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Benchmark of the WGAN-GP training step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one full WGAN-GP step of the reference's loop (wgan_gp.py:274-343): n_critic = 5
+critic updates on 5 distinct real batches + 1 generator update (after the first batch's critic
+update), at V = 175, L = 512, B = 64 per GPU, generator seq_len 512, dropout 0.3, synthetic
+tokens already resident in HBM.  value = n_critic * B_global / t_step (sequences/s, whole job).
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "sequence-to-graph-gan_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+V, L, B_PER_GPU, N_CRITIC, GEN_SEQ_LEN = 175, 512, 64, 5, 512
+# Algorithmic work of the dominant kernels (fp32 FLOP per sequence-step, both layers):
+# forward/tangent sweeps: W_hh0 h + W_ih1 y + W_hh1 h = 3 * 2 * 200 * 50; reverse sweeps likewise.
+SWEEP_FLOP_PER_STEP = 3 * 2 * 200 * 50
+FP32_PEAK_TFLOPS = 157.3       # MI355X fp32 vector = fp32 matrix peak
+
+
+def make_batches(seed: int, n: int, B: int, device, profile: str):
+    import common
+    from s2g.trainer import class_weight_sum
+    out = []
+    for i in range(n):
+        lengths = [L] * B if profile == "fixed" else common.adfa_lengths(seed + 100 + i, B, L).tolist()
+        tokens, labels, lengths = common.batch(seed + i, B, L, vocab=V, lengths=lengths)
+        out.append((tokens.to(torch.int32).to(device).contiguous(), labels.to(device),
+                    lengths.to(torch.int32).to(device), class_weight_sum(labels), labels))
+    return out
+
+
+def cpu_baseline(seconds_budget: float = 60.0):
+    """The CPU restatement of the reference step (oracle/, pinned to the reference's outputs by
+    tests/test_oracle_golden.py) timed on this host: ONE critic iteration (wgan_gp.py:277-318) at
+    B = 64, L = 512, V = 175, generator seq_len 512 -- a bounded sample of the same workload (a
+    full step is 5 of these + a generator update that costs <1% of one on the CPU)."""
+    import common
+    from oracle import wgan_gp_cpu as O
+    threads = torch.get_num_threads()
+    pg = common.generator_params(801, V, GEN_SEQ_LEN)
+    pd = common.critic_params(802, vocab=V)
+    bn = common.bn_buffers()
+    tokens, labels, lengths = common.batch(810, B_PER_GPU, L, vocab=V, lengths=[L] * B_PER_GPU)
+    nz = common.noise(820, B_PER_GPU, GEN_SEQ_LEN, vocab=V)
+    cfg = dict(vocab=V, tau=0.5, hard=False, lambda_gp=10.0, n_critic=N_CRITIC, gen_seq_len=GEN_SEQ_LEN)
+    opt = O.Adam(pd, 2e-4, 0.5, 0.999)
+    t0 = time.perf_counter()
+    O.critic_iteration(pg, bn, pd, opt, tokens, labels, lengths, nz["z"], nz["U"], nz["alpha"], cfg)
+    dt = time.perf_counter() - t0
+    return {"value": B_PER_GPU / dt, "unit": "sequences/s", "cores": threads, "kind": "port",
+            "sample": f"1 critic iteration (B=64, L=512, V=175, gen seq_len 512, no dropout) in {dt:.1f} s; "
+                      f"host has {os.cpu_count()} logical CPUs, torch used {threads} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--lengths", default="fixed", choices=["fixed", "adfa"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--drop-rate", type=float, default=0.3)
+    a = ap.parse_args()
+
+    from s2g import lib
+    from s2g.parallel import init_from_env
+    from s2g.trainer import WGANGPTrainer
+    lib.get()                                    # fail loudly if libs2g.so is missing
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
+    comm, rank, local, world = init_from_env("nccl")
+    if world != max(a.gpus, 1):
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    import common
+    tr = WGANGPTrainer(V, GEN_SEQ_LEN, dev, lr=2e-4, b1=0.5, b2=0.999, lambda_gp=10.0, tau=0.5, hard=False,
+                       n_critic=N_CRITIC, drop_rate=a.drop_rate, comm=comm)
+    tr.G.load(common.generator_params(801, V, GEN_SEQ_LEN))      # same initial weights on every rank
+    tr.D.load(common.critic_params(802, vocab=V))
+    torch.manual_seed(42 + rank)                                  # per-rank noise streams
+    pool = make_batches(1000 + 7919 * rank, 2 * N_CRITIC, B_PER_GPU, dev, a.lengths)
+    if comm is not None:
+        from s2g.parallel import global_wsum
+        pool = [(t, lab, ln, global_wsum(lab_cpu, comm, dev), lab_cpu) for (t, lab, ln, _, lab_cpu) in pool]
+
+    # per-kernel timing of the dominant kernel (forward sweep over 3B sequences): HIP events on the
+    # stream the kernel is launched on, recorded inside the timed region
+    ev = []
+    tr.D.timed_events = ev
+
+    def one_step(k):
+        batches = [pool[(k * N_CRITIC + i) % len(pool)][:4] for i in range(N_CRITIC)]
+        tr.full_step(batches)
+
+    for k in range(a.warmup):
+        one_step(k)
+    ev.clear()
+    if comm is not None:
+        comm.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        one_step(a.warmup + k)
+    if comm is not None:
+        comm.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if comm is not None:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax[0])
+
+    if rank == 0:
+        ms_per_step = dt / a.steps * 1e3
+        seqs = N_CRITIC * B_PER_GPU * world * a.steps
+        # dominant kernel: s2g_k_lstm2_fwd on 3B sequences x 512 steps
+        durs = [s.elapsed_time(e) for s, e in ev]
+        kern_ms = sum(durs) / max(len(durs), 1)
+        live = 0
+        for p in pool[:N_CRITIC]:
+            live += int(p[2].sum()) * 2 + B_PER_GPU * GEN_SEQ_LEN      # real + interp lengths, fake Tf
+        live /= N_CRITIC                                                # sequence-steps per launch (average)
+        flops = live * SWEEP_FLOP_PER_STEP
+        achieved = flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
+        line = {
+            "metric": "WGAN-GP train sequences/sec at V=175 L=512", "value": seqs / dt, "unit": "sequences/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "full WGAN-GP step = 5 critic updates (real+fake+gradient penalty) + 1 generator "
+                                   "update; V=175, L=512, B=64 per GPU, generator seq_len 512, tau 0.5, lambda_gp 10, "
+                                   f"critic dropout {a.drop_rate}, lengths {a.lengths}",
+                       "global_batch": B_PER_GPU * world, "seq_len": L, "parallelism": f"dp{world}"},
+            "ms_per_critic_iteration_est": ms_per_step / (N_CRITIC + 0.3),
+            "roofline": {"bound": "mfma", "kernel": "s2g_k_lstm2_fwd (forward sweep, 3B sequences)",
+                         "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP32_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": kern_ms,
+                         "launches_timed": len(durs),
+                         "note": "exact-fp32 recurrence on the VALU, one workgroup per sequence; peak = fp32 "
+                                 "vector/matrix peak; the sweep is dependency-chain bound (512 sequential steps)"},
+        }
+        if not a.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if comm is not None:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

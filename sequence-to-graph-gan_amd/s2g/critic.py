@@ -58,6 +58,7 @@ class CriticEngine:
         self.b0 = torch.empty(G4, device=device)
         self.b1 = torch.empty(G4, device=device)
         self.scratch = ops.Scratch(device)
+        self.timed_events = None      # list -> (start, end) HIP event pairs around the 3B-sequence forward sweep
         self._ws_key = None
         self.ws: Dict[str, torch.Tensor] = {}
 
@@ -119,11 +120,18 @@ class CriticEngine:
         rows = x.numel() // self.V
         ops.gemm_raw(ptr(x), self.V, 1, ptr(self.WT0), G4, 1, ptr(out), G4, rows, G4, self.V)
 
-    def sweep_fwd(self, ws, desc_ptr, nseq, max_len, tokens, P, mask) -> None:
+    def sweep_fwd(self, ws, desc_ptr, nseq, max_len, tokens, P, mask, timed: bool = False) -> None:
         whh0, wih1, whh1 = self._w()
+        te = self.timed_events if timed else None
+        if te is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         call("s2g_lstm2_fwd", desc_ptr, nseq, max_len, ptr(tokens), ptr(self.WT0), ptr(P), ptr(mask), ptr(self.b0),
              ptr(self.b1), whh0, wih1, whh1, ptr(ws["gates0"]), ptr(ws["cell0"]), ptr(ws["gates1"]),
              ptr(ws["cell1"]), ptr(ws["hT"]), stream_ptr())
+        if te is not None:
+            e1.record()
+            te.append((e0, e1))
 
     def head_fwd(self, ws, nseq) -> None:
         p = self.params.views
@@ -230,7 +238,7 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         ws["xhat"] = torch.empty(B * T, V, device=eng.device)
     # sweep A on 3B sequences
     eng.project(fake, ws["Pf"])
-    eng.sweep_fwd(ws, dptr, 3 * B, Tw, tokens, ws["Pf"], mask)
+    eng.sweep_fwd(ws, dptr, 3 * B, Tw, tokens, ws["Pf"], mask, timed=True)
     eng.head_fwd(ws, 3 * B)
     inv_n = 1.0 / float(n_global)
     call("s2g_critic_loss", ptr(ws["out"]), ptr(labels), B, inv_n, inv_wsum, class_w[0], class_w[1],

@@ -7,6 +7,10 @@ from __future__ import annotations
 import ctypes
 import os
 
+# torch ships its own HIP runtime (libamdhip64); it must be the first one loaded so that
+# libs2g.so binds to the same runtime instance that owns torch's streams and allocations.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libs2g.so")
 

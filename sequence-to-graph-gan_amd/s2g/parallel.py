@@ -1,0 +1,74 @@
+"""Data-parallel layer: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI
+on ROCm; "gloo" for CPU rehearsals).  The reference is single-process (helper_tools.py:10-24);
+the batch dimension shards exactly because the critic is per-sample independent, and the three
+cross-sample couplings are handled explicitly:
+
+  * batch means (wgan_gp.py:313) and the penalty mean (:256): every rank normalises by the
+    GLOBAL batch size, so gradients combine with a plain SUM all-reduce;
+  * the weighted cross-entropy mean (wgan_gp.py:267-268) divides by the GLOBAL sum of class
+    weights (global_wsum);
+  * the generator's BatchNorm batch statistics (wgan_gp.py:150): per-feature sums are
+    all-reduced between the statistics kernel and the normalise kernel (forward and backward).
+
+Gradients travel as ONE flat fp32 bucket per network (critic 66 k floats: latency-bound, one
+message; generator up to 46 M floats: bandwidth-bound, one large message so RCCL can use all
+xGMI links)."""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+class DistComm:
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def allreduce(self, t: torch.Tensor) -> None:
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    def barrier(self) -> None:
+        if self.world > 1:
+            dist.barrier(group=self.group)
+
+
+def init_from_env(backend: str = "nccl"):
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torch.distributed.run).
+    Returns (comm or None, rank, local_rank, world)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world <= 1:
+        return None, 0, local, 1
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    if not dist.is_initialized():
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return DistComm(), rank, local, world
+
+
+def shard(n_global: int, rank: int, world: int):
+    """Contiguous batch shard [lo, hi) of this rank (equal shards; n_global % world == 0)."""
+    if n_global % world:
+        raise ValueError("global batch must divide evenly over the ranks")
+    per = n_global // world
+    return rank * per, (rank + 1) * per
+
+
+def global_wsum(labels_cpu: torch.Tensor, comm, device=None) -> float:
+    """Global sum of the class weights [1,2] over all ranks' labels (wgan_gp.py:267)."""
+    n1 = int((labels_cpu == 1).sum())
+    w = 1.0 * (labels_cpu.numel() - n1) + 2.0 * n1
+    if comm is None or comm.world == 1:
+        return w
+    t = torch.tensor([w], dtype=torch.float64, device=device or "cpu")
+    comm.allreduce(t)
+    return float(t[0])
