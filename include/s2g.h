@@ -122,6 +122,9 @@ int s2g_generator_loss(const float* out, const long long* labels, int B, float i
 int s2g_one_hot(const int* tokens, const int* lengths, int T, float* x, long rows, int V, void* stream);
 int s2g_gp_interp(const int* tokens, const int* lengths, const float* fake, const float* alpha, int B, int T,
                   int Tf, int V, float* xhat, void* stream);
+/* same with the real batch given dense [B,T,V] (the argument compute_gradient_penalty receives) */
+int s2g_gp_interp_dense(const float* real, const int* lengths, const float* fake, const float* alpha, int B,
+                        int T, int Tf, int V, float* xhat, void* stream);
 /* per sample b: norms[b] = |g_b|, pen[b] = (|g_b| - 1)^2 and, when scale_in_place,
  * g_b <- upstream * 2 (|g_b| - 1) / (n_batch |g_b|) * g_b */
 int s2g_gp_norm_penalty(float* g, int B, long per_sample, float upstream, float n_batch, float* pen,

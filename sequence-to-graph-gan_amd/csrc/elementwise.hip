@@ -397,3 +397,22 @@ extern "C" __global__ void s2g_k_critic_batch_desc(const int* __restrict__ lengt
   }
   seqs[i] = s;
 }
+
+// Dense form of the interpolation for callers that hold the real batch as a dense [B,T,V] tensor
+// (compute_gradient_penalty's signature, wgan_gp.py:225-239).
+extern "C" __global__ void s2g_k_gp_interp_dense(const float* __restrict__ real, const int* __restrict__ lengths,
+                                                 const float* __restrict__ fake, const float* __restrict__ alpha,
+                                                 int B, int T, int Tf, int V, float* __restrict__ xhat) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * T * V) return;
+  int v = (int)(i % V);
+  long r = i / V;
+  int t = (int)(r % T), b = (int)(r / T);
+  float out = 0.0f;
+  if (t < lengths[b]) {
+    float a = alpha[b];
+    float f = (t < Tf) ? fake[((long)b * Tf + t) * V + v] : 0.0f;
+    out = a * real[i] + (1.0f - a) * f;
+  }
+  xhat[i] = out;
+}

@@ -255,3 +255,11 @@ int s2g_adam(float* p, const float* g, float* m, float* v, long n, float lr, flo
 }
 
 }  // extern "C"
+
+extern "C" int s2g_gp_interp_dense(const float* real, const int* lengths, const float* fake, const float* alpha,
+                                   int B, int T, int Tf, int V, float* xhat, void* stream) {
+  if (!real || !lengths || !fake || !alpha || !xhat || B <= 0 || T <= 0 || Tf <= 0 || V <= 0) return -1;
+  hipLaunchKernelGGL(s2g_k_gp_interp_dense, dim3(cdiv((long)B * T * V, 256)), dim3(256), 0, ST(stream), real,
+                     lengths, fake, alpha, B, T, Tf, V, xhat);
+  return LAUNCH_OK();
+}

@@ -82,6 +82,11 @@ class CriticEngine:
         key = (nseq, Tw, so_seqs)
         if self._ws_key == key:
             return self.ws
+        self.ws, self._ws_key = self.fresh_workspace(nseq, Tw, so_seqs), key
+        return self.ws
+
+    def fresh_workspace(self, nseq: int, Tw: int, so_seqs: int) -> Dict[str, torch.Tensor]:
+        """A private set of buffers (the autograd bridges keep one per outstanding forward)."""
         dev = self.device
         rows, so_rows = nseq * Tw, so_seqs * Tw
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)  # noqa: E731
@@ -93,7 +98,6 @@ class CriticEngine:
                       celld0=z(so_rows, G4), celld1=z(so_rows, G4), abar0=z(so_rows, G4), abar1=z(so_rows, G4),
                       hdotT=z(so_seqs, H), G=z(so_rows, self.V), Pv=z(so_rows, G4), pen=z(so_seqs),
                       norms=z(so_seqs))
-        self.ws, self._ws_key = ws, key
         return ws
 
     def workspace_g(self, B: int, Tf: int) -> Dict[str, torch.Tensor]:

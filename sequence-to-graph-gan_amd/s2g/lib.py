@@ -50,6 +50,7 @@ SIGNATURES = {
     "s2g_generator_loss": [P, P, I, F, F, F, F, P, P, P],
     "s2g_one_hot": [P, P, I, P, L, I, P],
     "s2g_gp_interp": [P, P, P, P, I, I, I, I, P, P],
+    "s2g_gp_interp_dense": [P, P, P, P, I, I, I, I, P, P],
     "s2g_gp_norm_penalty": [P, I, L, F, F, P, P, I, P],
     "s2g_gp_scale": [P, P, P, F, L, P, I, P],
     "s2g_embed_mul": [P, P, P, P, I, I, P],

@@ -37,16 +37,20 @@ def dropout_mask(rows: int, p: float, device) -> Optional[torch.Tensor]:
 class WGANGPTrainer:
     def __init__(self, vocab: int, gen_seq_len: int, device, lr: float = 2e-4, b1: float = 0.5, b2: float = 0.999,
                  lambda_gp: float = 10.0, tau: float = 0.5, hard: bool = False, n_critic: int = 5,
-                 drop_rate: float = 0.3, comm=None):
+                 drop_rate: float = 0.3, comm=None, gen_engine=None, critic_engine=None):
         self.device = torch.device(device)
         self.comm = comm or NoComm()
-        self.G = GeneratorEngine(vocab, gen_seq_len, self.device, comm=self.comm)
-        self.D = CriticEngine(vocab, self.device)
+        self.G = gen_engine or GeneratorEngine(vocab, gen_seq_len, self.device, comm=self.comm)
+        self.G.comm = self.comm
+        self.D = critic_engine or CriticEngine(vocab, self.device)
+        self.D.repack()
         self.lr, self.b1, self.b2, self.eps = lr, b1, b2, 1e-8
         self.lambda_gp, self.tau, self.hard, self.n_critic, self.drop_rate = lambda_gp, tau, hard, n_critic, drop_rate
         self.V, self.L = vocab, gen_seq_len
-        self.mD, self.vD = torch.zeros_like(self.D.params.flat), torch.zeros_like(self.D.params.flat)
-        self.mG, self.vG = torch.zeros_like(self.G.params.flat), torch.zeros_like(self.G.params.flat)
+        self.mD_named, self.vD_named = self.D.params.like(), self.D.params.like()   # Adam moments (named views)
+        self.mG_named, self.vG_named = self.G.params.like(), self.G.params.like()
+        self.mD, self.vD = self.mD_named.flat, self.vD_named.flat
+        self.mG, self.vG = self.mG_named.flat, self.vG_named.flat
         self.tD = 0
         self.tG = 0
         self.last: Dict[str, torch.Tensor] = {}

@@ -1,0 +1,282 @@
+"""MI355X-native WGAN-GP trainer with the module surface of the reference's wgan_gp.py:
+CustomSoftmax, Generator, Discriminator, compute_gradient_penalty, train_wgan, main -- same
+names, argument meaning, state_dict keys and checkpoint files (reference wgan_gp.py:22-447), so
+`from wgan_gp import Generator` (generate_fake_data.py:8) and `from wgan_gp import CustomSoftmax`
+(wgan.py:16) keep working.  All arithmetic runs in the HIP kernels of libs2g (include/s2g.h); the
+modules need a GPU tensor and raise on CPU tensors (there is deliberately no CPU path).
+
+    python3 wgan_gp.py --vocab_size=175 --seq_len=512 --batch_size=64 --lr=0.0002 \
+        --lambda_gp=10.0 --tau=0.5 --epochs=500
+"""
+import os
+import sys
+
+import torch
+import torch.nn as nn
+from torch import rand, randn  # noqa: F401  (module-level names, as in the reference, so callers can patch them)
+from torch.nn.utils.rnn import PackedSequence, pad_packed_sequence
+from torch.utils.data import DataLoader
+
+_PKG = os.path.join(os.path.dirname(os.path.abspath(__file__)), "sequence-to-graph-gan_amd")
+if _PKG not in sys.path:
+    sys.path.insert(0, _PKG)
+
+from config import get_args  # noqa: E402
+from s2g import data as s2g_data  # noqa: E402
+from s2g import ops  # noqa: E402
+from s2g.critic import CriticEngine  # noqa: E402
+from s2g.generator import GeneratorEngine  # noqa: E402
+from s2g.lib import S2GError  # noqa: E402
+from s2g.modules import CriticFn, GeneratorFn, GradientPenaltyFn, SamplerFn, adopt  # noqa: E402
+from s2g.trainer import WGANGPTrainer, class_weight_sum  # noqa: E402
+
+
+class CustomSoftmax(nn.Module):
+    """Gumbel-softmax / relaxed (temperature) softmax / plain softmax sampler (reference :22-104)."""
+
+    def __init__(self, act="gumbel_softmax"):
+        super().__init__()
+        self.act = act
+
+    def forward(self, logits, tau, hard):
+        if self.act == "gumbel_softmax":
+            return self.gumbel_softmax(logits, tau, hard)
+        elif self.act == "relaxed_bernoulli":
+            return self.relaxed_bernoulli(logits, tau)
+        return SamplerFn.apply(logits, None, 1.0, 2, False)
+
+    def _uniform(self, logits):
+        # the reference draws on the CPU generator and copies (:58): same seed -> same noise
+        return torch.rand(logits.size()).to(logits.device)
+
+    def sample_gumbel(self, logits, eps=1e-10):
+        """Gumbel(0,1) noise as a tensor (reference :56-61).  Auxiliary accessor only: the sampling
+        path fuses this transform into the kernel and never materialises it."""
+        U = eps + (1 - eps) * self._uniform(logits)
+        return -torch.log(-torch.log(U + 1e-20) + 1e-20)
+
+    def gumbel_softmax_sample(self, logits, tau):
+        return SamplerFn.apply(logits, self._uniform(logits), float(tau), 0, False)
+
+    def gumbel_softmax(self, logits, tau, hard=False):
+        return SamplerFn.apply(logits, self._uniform(logits), float(tau), 0, bool(hard))
+
+    @staticmethod
+    def anneal_tau_(initial_tau, final_tau, current_epoch, total_epochs, anneal_interval):
+        if current_epoch % anneal_interval == 0:
+            return initial_tau - (initial_tau - final_tau) * (current_epoch / total_epochs)
+        return initial_tau
+
+    def relaxed_bernoulli(self, logits, tau=1, dim=-1):
+        if dim not in (-1, logits.dim() - 1):
+            raise S2GError("relaxed_bernoulli: only the last dimension is supported")
+        return SamplerFn.apply(logits, None, float(tau), 1, False)
+
+
+class Generator(nn.Module):
+    """Reference :141-171.  `seq_len` is an extra keyword; the default 120 is the reference's
+    hard-coded value, so checkpoints stay loadable by generate_fake_data.py:28-29."""
+
+    def __init__(self, vocab_size, n_classes=2, seq_len=120):
+        super(Generator, self).__init__()
+        self.latent_dim = 100
+        self.seq_len = seq_len
+        self.vocab_size = vocab_size
+        self.n_classes = n_classes
+
+        def block(in_feat, out_feat, normalize=True):
+            layers = [nn.Linear(in_feat, out_feat)]
+            if normalize:
+                layers.append(nn.BatchNorm1d(out_feat, 0.8))
+            layers.append(nn.LeakyReLU(0.2, inplace=True))
+            return layers
+
+        self.model = nn.Sequential(
+            *block(self.latent_dim, 128, normalize=False),
+            *block(128, 256),
+            *block(256, 512),
+            nn.Linear(512, self.vocab_size * self.seq_len)
+        )
+        self.label_embedding = nn.Embedding(n_classes, self.latent_dim)
+        self.gumbel_softmax = CustomSoftmax()
+        self._eng = None
+
+    def engine(self, device) -> GeneratorEngine:
+        if self._eng is None or self._eng.device != device:
+            self._eng = GeneratorEngine(self.vocab_size, self.seq_len, device, self.n_classes)
+        eng = self._eng
+        adopt(self, eng.params)
+        named = dict(self.named_buffers())
+        for k, buf in eng.buffers.items():
+            if named[k].data_ptr() != buf.data_ptr():
+                buf.copy_(named[k].data.to(device))
+                named[k].data = buf
+        return eng
+
+    def forward(self, noise, labels, tau, hard):
+        if not noise.is_cuda:
+            raise S2GError("Generator.forward needs GPU tensors (MI355X-only implementation, no CPU path)")
+        eng = self.engine(noise.device)
+        U = None
+        if self.gumbel_softmax.act == "gumbel_softmax":
+            U = torch.rand((noise.shape[0], self.seq_len, self.vocab_size)).to(noise.device)
+        y = GeneratorFn.apply(eng, noise, labels, U, float(tau), bool(hard), self.training,
+                              self.gumbel_softmax.act, *[p for _, p in self.named_parameters()])
+        if self.training:
+            for m in (self.model[3], self.model[6]):
+                m.num_batches_tracked += 1
+        return y
+
+
+class Discriminator(nn.Module):
+    """Reference :175-223: nn.LSTM(input, hidden=50, layers=2, dropout) -> last layer's final hidden
+    state -> Linear(50, num_classes + 1).  Accepts a PackedSequence or a dense [B,T,V] tensor."""
+
+    def __init__(self, input_size, hidden_size, num_layers, num_classes, drop_rate=0.3):
+        super(Discriminator, self).__init__()
+        if hidden_size != 50 or num_layers != 2 or num_classes != 2:
+            raise S2GError("the HIP critic is specialised to hidden_size=50, num_layers=2, num_classes=2 "
+                           "(the configuration wgan_gp.main builds, reference :393-400)")
+        self.hidden_size = hidden_size
+        self.num_layers = num_layers
+        self.input_size = input_size
+        self.drop_rate = drop_rate
+        self.lstm = nn.LSTM(input_size, hidden_size, num_layers, batch_first=True, dropout=drop_rate)
+        self.fc = nn.Linear(self.hidden_size, num_classes + 1)
+        self._eng = None
+
+    def engine(self, device) -> CriticEngine:
+        if self._eng is None or self._eng.device != device:
+            self._eng = CriticEngine(self.input_size, device)
+        adopt(self, self._eng.params)
+        return self._eng
+
+    def dropout_mask(self, B, T, device):
+        if not self.training or self.drop_rate <= 0.0:
+            return None
+        return (torch.rand(B, T, 50, device=device) >= self.drop_rate).float() / (1.0 - self.drop_rate)
+
+    def forward(self, packed_input, lengths=None):
+        if isinstance(packed_input, PackedSequence):
+            x, lens = pad_packed_sequence(packed_input, batch_first=True)
+        else:
+            x, lens = packed_input, None
+        if not x.is_cuda:
+            raise S2GError("Discriminator.forward needs GPU tensors (MI355X-only implementation, no CPU path)")
+        eng = self.engine(x.device)
+        mask = self.dropout_mask(x.shape[0], x.shape[1], x.device)
+        return CriticFn.apply(eng, x, lens, mask, *[p for _, p in self.named_parameters()])
+
+
+def compute_gradient_penalty(discriminator, encoded_padded_real_data, fake_data, labels, lengths):
+    """Gradient penalty of WGAN-GP (reference :225-257): returns a 0-dim tensor attached to the
+    graph; its backward yields the critic-parameter gradient of the penalty (second order)."""
+    alpha = rand((fake_data.size(0), 1, 1)).to(fake_data.device)
+    eng = discriminator.engine(fake_data.device)
+    B, T = encoded_padded_real_data.shape[0], encoded_padded_real_data.shape[1]
+    mask = discriminator.dropout_mask(B, T, fake_data.device)
+    return GradientPenaltyFn.apply(eng, encoded_padded_real_data, fake_data.detach(), alpha, torch.as_tensor(lengths),
+                                   mask, *[p for _, p in discriminator.named_parameters()])
+
+
+def _adam_hparams(optimizer):
+    g = optimizer.param_groups[0]
+    return g["lr"], g["betas"][0], g["betas"][1]
+
+
+def _export_adam(optimizer, module, flat_m, flat_v, step):
+    """Expose the fused Adam's moments through the torch optimizer's state_dict."""
+    for name, p in module.named_parameters():
+        if name in flat_m.views:
+            optimizer.state[p] = {"step": torch.tensor(float(step)), "exp_avg": flat_m.views[name],
+                                  "exp_avg_sq": flat_v.views[name]}
+
+
+def train_wgan(generator, discriminator, optimizer_G, optimizer_D, train_dataloader, val_loader, opt, device):
+    """Reference :261-382.  Same loop, prints and checkpoints; each batch's critic update and the
+    generator update (when i % n_critic == 0) run as the fused HIP step."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise S2GError("train_wgan needs an MI355X (device 'cuda'); there is no CPU path")
+    lr, b1, b2 = _adam_hparams(optimizer_D)
+    tr = WGANGPTrainer(opt.vocab_size, generator.seq_len, device, lr=lr, b1=b1, b2=b2, lambda_gp=opt.lambda_gp,
+                       tau=opt.tau, hard=bool(opt.hard), n_critic=opt.n_critic,
+                       drop_rate=getattr(discriminator, "drop_rate", 0.3),
+                       gen_engine=generator.engine(device), critic_engine=discriminator.engine(device))
+    from tqdm import tqdm
+    from sklearn.metrics import f1_score
+
+    for epoch in range(1, opt.epochs + 1):
+        generator.train()
+        discriminator.train()
+        for i, (padded_sequences, labels, lengths) in enumerate(tqdm(train_dataloader)):
+            wsum = class_weight_sum(labels)
+            tok = padded_sequences.to(torch.int32).to(device).contiguous()
+            lab = labels.to(device)
+            ln = lengths.to(torch.int32).to(device)
+            # the reference draws z / U / alpha on the CPU generator and copies them (:291, :58, :228)
+            z = randn(tok.shape[0], generator.latent_dim).to(device)
+            U = torch.rand((tok.shape[0], generator.seq_len, generator.vocab_size)).to(device)
+            alpha = rand((tok.shape[0], 1, 1)).to(device)
+            tr.critic_step(tok, lab, ln, wsum, z=z, U=U, alpha=alpha.view(-1))
+            if i % opt.n_critic == 0:
+                U2 = torch.rand((tok.shape[0], generator.seq_len, generator.vocab_size)).to(device)
+                tr.generator_step(U=U2)
+                print(
+                    "[Epoch %d/%d] [Batch %d/%d] [D loss: %f] [G loss: %f]"
+                    % (epoch, opt.epochs, i, len(train_dataloader), tr.d_loss().item(), tr.g_loss().item())
+                )
+                if epoch % 5 == 0:
+                    torch.save(generator.state_dict(), f"saved_models/wgan_generator_{epoch}.pth")
+                if epoch % 5 == 0:
+                    with torch.no_grad():
+                        discriminator.eval()
+                        f1_scores = []
+                        for _, (vp, vl, vlen) in enumerate(val_loader):
+                            real = torch.nn.functional.one_hot(vp, opt.vocab_size).float().to(device)
+                            out = discriminator(torch.nn.utils.rnn.pack_padded_sequence(
+                                real, vlen, batch_first=True, enforce_sorted=False), vlen)
+                            preds = torch.argmax(out[:, 1:], dim=1).detach().cpu().tolist()
+                            f1_scores.append(f1_score(preds, vl.cpu().tolist()))
+                        avg_f1_score = torch.mean(torch.tensor(f1_scores, dtype=torch.float32))
+                        print(f"f1 score: {avg_f1_score:.4f}")
+                        discriminator.train()
+    for m in (generator.model[3], generator.model[6]):
+        m.num_batches_tracked.fill_(tr.G.num_batches_tracked)
+    _export_adam(optimizer_D, discriminator, tr.mD_named, tr.vD_named, tr.tD)
+    _export_adam(optimizer_G, generator, tr.mG_named, tr.vG_named, tr.tG)
+    return tr
+
+
+def main():
+    opt = get_args()
+    vocabs = s2g_data.load_vocabulary()
+    input_size = len(vocabs)
+    device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+    if device.type != "cuda":
+        raise S2GError("wgan_gp.py needs an MI355X (torch.cuda.is_available() is False)")
+
+    discriminator = Discriminator(input_size, 50, 2, 2, drop_rate=opt.drop_rate).to(device)
+    generator = Generator(opt.vocab_size, 2, seq_len=opt.gen_seq_len).to(device)
+    optimizer_G = torch.optim.Adam(generator.parameters(), lr=opt.lr, betas=(opt.b1, opt.b2))
+    optimizer_D = torch.optim.Adam(discriminator.parameters(), lr=opt.lr, betas=(opt.b1, opt.b2))
+
+    s2g_data.set_random_seeds(seed_value=42)
+    dataset_folder = os.path.join(os.getcwd(), "data")
+    train_data, train_labels = s2g_data.load_dataset(os.path.join(dataset_folder, "train_dataset.json"))
+    test_data, test_labels = s2g_data.load_dataset(os.path.join(dataset_folder, "test_dataset.json"))
+    train_data = s2g_data.encode_sequences(train_data, vocabs)
+    test_data = s2g_data.encode_sequences(test_data, vocabs)
+    train_labels, test_labels = s2g_data.encode_labels(train_labels, test_labels)
+    train_data, train_labels = s2g_data.sample_equal_data(train_data, train_labels)
+
+    train_dataset = s2g_data.CustomSequenceDataset(train_data, train_labels, length=opt.seq_len)
+    test_dataset = s2g_data.CustomSequenceDataset(test_data, test_labels, opt.seq_len)
+    train_loader = DataLoader(train_dataset, batch_size=opt.batch_size, collate_fn=s2g_data.collate_fn, shuffle=True)
+    val_loader = DataLoader(test_dataset, batch_size=opt.batch_size, collate_fn=s2g_data.collate_fn, shuffle=False)
+    os.makedirs("saved_models", exist_ok=True)
+    train_wgan(generator, discriminator, optimizer_G, optimizer_D, train_loader, val_loader, opt, device)
+
+
+if __name__ == "__main__":
+    main()
