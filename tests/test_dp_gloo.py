@@ -1,0 +1,105 @@
+"""Data-parallel conventions of s2g/parallel.py rehearsed with 2 CPU processes over gloo: each rank
+takes a contiguous shard of the batch, normalises its loss by the GLOBAL batch size and the GLOBAL
+class-weight sum, all-reduces per-feature BatchNorm sums, and SUM-all-reduces gradients; the
+result must equal the single-process step on the whole batch (oracle arithmetic, float64)."""
+import os
+import socket
+
+import torch
+import torch.multiprocessing as mp
+import torch.nn.functional as F
+
+import common
+
+WORLD = 2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _sync_bn_forward(x, gamma, beta, comm, n_global, eps=0.8):
+    """what GeneratorEngine._bn does: local sums -> all-reduce -> normalise."""
+    stats = torch.cat([x.sum(0), (x * x).sum(0)])
+    comm.allreduce(stats)
+    Fdim = x.shape[1]
+    mean = stats[:Fdim] / n_global
+    var = stats[Fdim:] / n_global - mean * mean
+    return (x - mean) / torch.sqrt(var + eps) * gamma + beta
+
+
+def _dp_critic_loss(O, p, real, lengths, fake, labels, alpha, lam, n_global, wsum):
+    """local share of d_loss with global normalisers (what critic_iteration is given)."""
+    out_r = O.critic_forward(p, real, lengths)
+    out_f = O.critic_forward(p, fake, None)
+    fake_p = O.pad_or_crop_time(fake, real.shape[1])
+    xh = (alpha * real + (1 - alpha) * fake_p).detach().requires_grad_(True)
+    d = O.critic_forward(p, xh, lengths)[:, 0]
+    (g,) = torch.autograd.grad(d, xh, torch.ones_like(d), create_graph=True)
+    pen = ((g.reshape(g.shape[0], -1).norm(2, dim=1) - 1) ** 2).sum() / n_global
+    w = torch.tensor([1.0, 2.0], dtype=real.dtype)
+
+    def ce_sum(out):
+        logp = F.log_softmax(F.softmax(out[:, 1:], -1), -1)
+        return -(w[labels] * logp[torch.arange(len(labels)), labels]).sum() / wsum
+    return (-out_r[:, 0].sum() + out_f[:, 0].sum()) / n_global + lam * pen + 0.5 * (ce_sum(out_r) + ce_sum(out_f))
+
+
+def _worker(rank, port, ret):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(WORLD), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from oracle import wgan_gp_cpu as O
+    from s2g.parallel import global_wsum, init_from_env, shard
+    comm, r, _, world = init_from_env("gloo")
+    assert (r, world) == (rank, WORLD) and comm.world == WORLD
+    B, T, Tf, V = 8, 10, 6, 23
+    dt = torch.float64
+    p = {k: v.requires_grad_(True) for k, v in common.critic_params(91, vocab=V, scale=2.0, dtype=dt).items()}
+    tokens, labels, lengths = common.batch(92, B, T, vocab=V, min_len=2)
+    g = common.gen(93)
+    fake = torch.softmax(torch.randn((B, Tf, V), generator=g, dtype=dt), -1)
+    alpha = torch.rand((B, 1, 1), generator=g, dtype=dt)
+    real = F.one_hot(tokens, V).to(dt)
+    lo, hi = shard(B, rank, world)
+    wsum = global_wsum(labels[lo:hi], comm)
+    assert wsum == float(1.0 * (labels == 0).sum() + 2.0 * (labels == 1).sum())
+    loss = _dp_critic_loss(O, p, real[lo:hi], lengths[lo:hi], fake[lo:hi], labels[lo:hi], alpha[lo:hi], 10.0, B, wsum)
+    names = list(p)
+    grads = torch.autograd.grad(loss, [p[n] for n in names])
+    flat = torch.cat([x.reshape(-1) for x in grads])            # one flat bucket
+    comm.allreduce(flat)
+    lt = loss.detach().reshape(1).clone()
+    comm.allreduce(lt)
+
+    # SyncBN
+    x = torch.randn((B, 5), generator=common.gen(94), dtype=dt)
+    gamma, beta = torch.rand(5, generator=g, dtype=dt) + 0.5, torch.rand(5, generator=g, dtype=dt)
+    y_local = _sync_bn_forward(x[lo:hi], gamma, beta, comm, float(B))
+
+    if rank == 0:
+        p1 = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
+        full, _ = O.critic_loss(p1, real, lengths, fake, labels, alpha, 10.0)
+        gfull = torch.autograd.grad(full, [p1[n] for n in names])
+        ref = torch.cat([x.reshape(-1) for x in gfull])
+        mean, var = x.mean(0), x.var(0, unbiased=False)
+        y_ref = ((x - mean) / torch.sqrt(var + 0.8) * gamma + beta)[lo:hi]
+        ret["grad_err"] = float((flat - ref).norm() / ref.norm())
+        ret["loss_err"] = abs(float(lt[0]) - float(full))
+        ret["bn_err"] = float((y_local - y_ref).abs().max())
+    comm.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_step_equals_single_rank():
+    port = _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(port, ret), nprocs=WORLD, join=True)
+        assert ret["grad_err"] < 1e-10, dict(ret)
+        assert ret["loss_err"] < 1e-10, dict(ret)
+        assert ret["bn_err"] < 1e-10, dict(ret)
