@@ -19,7 +19,7 @@
 #define BM 64
 #define BN 64
 #define BK 32
-#define LDT (BK + 1)
+#define LDS_LD 68   // k-major tiles [BK][64 + 4]: 16-byte rows, float4 stores stay aligned
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -32,91 +32,168 @@ struct GemmArgs {
   float alpha;
 };
 
-template <bool A_KFAST, bool B_KFAST>
-__global__ __launch_bounds__(256) void s2g_k_gemm_f32(GemmArgs g) {
-  __shared__ float As[BM * LDT];
-  __shared__ float Bs[BN * LDT];
+// (sequence, step) position of a reduction index under the segT mapping, advanced incrementally so
+// the inner loop carries no integer division.
+struct SegPos {
+  int b, t;
+  __device__ __forceinline__ void init(int k, int segT) {
+    if (segT > 0) { b = k / segT; t = k - b * segT; } else { b = 0; t = k; }
+  }
+  __device__ __forceinline__ void advance(int dk, int segT) {
+    t += dk;
+    if (segT > 0) while (t >= segT) { t -= segT; ++b; }
+  }
+};
+
+// Loader of one operand tile [BK][64] into k-major LDS.
+//   MODE 0: generic strides, scalar loads; lanes run along the non-k index (m or n).
+//   MODE 1: non-k index contiguous in memory (stride 1) and 16-byte aligned rows: float4 along it.
+//   MODE 2: k contiguous in memory (stride 1), rows 16-byte aligned, no segT mapping: float4 along k.
+//   MODE 3: k contiguous in memory but rows unaligned (e.g. 175-wide rows): scalar loads with the
+//           lanes running along k, so a wave still reads 128-byte segments.
+template <int MODE>
+struct TileLoader {
+  float r[8];
+  SegPos pos;      // position of this thread's first k of the current K-block
+  int x, kq;       // x: non-k index inside the tile; kq: first k inside the K-block
+
+  __device__ __forceinline__ void setup(int tid, int kbeg, int segT) {
+    if (MODE == 1) { x = (tid & 15) * 4; kq = tid >> 4; }        // k = kq, kq + 16
+    else if (MODE == 2) { x = tid & 63; kq = (tid >> 6) * 8; }   // k = kq .. kq + 7
+    else if (MODE == 3) { x = tid >> 5; kq = tid & 31; }         // x = x + 8 e, k = kq
+    else { x = tid & 63; kq = tid >> 6; }                        // k = kq + 4 e
+    pos.init(kbeg + kq, segT);
+  }
+  // P: base pointer; sx / sk: strides of the non-k / k index; seg: rows per sequence of this operand;
+  // x0: tile origin; X: bound of the non-k index; shift: read step t-1, zero at t == 0.
+  __device__ __forceinline__ void load(const float* P, long sx, long sk, int seg, int segT, bool shift, int x0,
+                                       int X, int k0, int kend) {
+    const int xi = x0 + x;
+    if (MODE == 1) {
+      SegPos q = pos;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int k = k0 + kq + 16 * e;
+        long kr = segT > 0 ? (long)q.b * seg + q.t : (long)k;
+        bool ok = (xi + 3 < X) && (k < kend);
+        if (shift) { ok = ok && q.t != 0; kr -= 1; }
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) v = *reinterpret_cast<const float4*>(P + kr * sk + xi);
+        else if (xi < X && k < kend && !(shift && q.t == 0)) {     // ragged edge: element-wise
+          const float* src = P + kr * sk + xi;
+          v.x = src[0];
+          if (xi + 1 < X) v.y = src[1];
+          if (xi + 2 < X) v.z = src[2];
+        }
+        r[4 * e] = v.x; r[4 * e + 1] = v.y; r[4 * e + 2] = v.z; r[4 * e + 3] = v.w;
+        q.advance(16, segT);
+      }
+    } else if (MODE == 2) {
+      const int k = k0 + kq;
+      const float* src = P + (long)xi * sx + k;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (xi < X) {
+          if (k + 4 * e + 3 < kend) v = *reinterpret_cast<const float4*>(src + 4 * e);
+          else {
+            if (k + 4 * e < kend) v.x = src[4 * e];
+            if (k + 4 * e + 1 < kend) v.y = src[4 * e + 1];
+            if (k + 4 * e + 2 < kend) v.z = src[4 * e + 2];
+          }
+        }
+        r[4 * e] = v.x; r[4 * e + 1] = v.y; r[4 * e + 2] = v.z; r[4 * e + 3] = v.w;
+      }
+    } else if (MODE == 3) {
+      const int k = k0 + kq;
+      long kr = segT > 0 ? (long)pos.b * seg + pos.t : (long)k;
+      bool okk = k < kend;
+      if (shift) { okk = okk && pos.t != 0; kr -= 1; }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int xe = xi + 8 * e;
+        r[e] = (okk && xe < X) ? P[kr * sk + (long)xe * sx] : 0.0f;
+      }
+    } else {
+      SegPos q = pos;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = k0 + kq + 4 * e;
+        long kr = segT > 0 ? (long)q.b * seg + q.t : (long)k;
+        bool ok = (xi < X) && (k < kend);
+        if (shift) { ok = ok && q.t != 0; kr -= 1; }
+        r[e] = ok ? P[kr * sk + (long)xi * sx] : 0.0f;
+        q.advance(4, segT);
+      }
+    }
+    pos.advance(BK, segT);
+  }
+  __device__ __forceinline__ void store(float* S) const {
+    if (MODE == 1) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+        *reinterpret_cast<float4*>(S + (kq + 16 * e) * LDS_LD + x) = make_float4(r[4 * e], r[4 * e + 1], r[4 * e + 2], r[4 * e + 3]);
+    } else if (MODE == 2) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) S[(kq + e) * LDS_LD + x] = r[e];
+    } else if (MODE == 3) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) S[kq * LDS_LD + x + 8 * e] = r[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) S[(kq + 4 * e) * LDS_LD + x] = r[e];
+    }
+  }
+};
+
+template <int AMODE, int BMODE>
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const int by, const int bz, float* As,
+                                          float* Bs) {
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int wr = wave >> 1, wc = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int kbeg = blockIdx.z * g.kchunk;
+  const int m0 = by * BM, n0 = bx * BN;
+  const int kbeg = bz * g.kchunk;
   const int kend = min(g.K, kbeg + g.kchunk);
 
-  float ra[8], rb[8];
-  auto gload = [&](int k0) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      int idx = tid + 256 * e;
-      int kk = A_KFAST ? (idx & (BK - 1)) : (idx >> 6);
-      int mm = A_KFAST ? (idx >> 5) : (idx & (BM - 1));
-      int m = m0 + mm, k = k0 + kk;
-      long ka = k;
-      if (g.segT > 0) ka = (long)(k / g.segT) * g.a_seg + (k % g.segT);
-      ra[e] = (m < g.M && k < kend) ? g.A[(long)m * g.sam + ka * g.sak] : 0.0f;
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      int idx = tid + 256 * e;
-      int kk = B_KFAST ? (idx & (BK - 1)) : (idx >> 6);
-      int nn = B_KFAST ? (idx >> 5) : (idx & (BN - 1));
-      int n = n0 + nn, k = k0 + kk;
-      bool ok = (n < g.N && k < kend);
-      long kr = k;
-      if (g.segT > 0) {
-        int t = k % g.segT;
-        kr = (long)(k / g.segT) * g.b_seg + t;
-        if (g.shift) { ok = ok && t != 0; kr -= 1; }
-      }
-      rb[e] = ok ? g.B[kr * g.sbk + (long)n * g.sbn] : 0.0f;
-    }
-  };
-  auto sstore = [&]() {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      int idx = tid + 256 * e;
-      int kk = A_KFAST ? (idx & (BK - 1)) : (idx >> 6);
-      int mm = A_KFAST ? (idx >> 5) : (idx & (BM - 1));
-      As[mm * LDT + kk] = ra[e];
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      int idx = tid + 256 * e;
-      int kk = B_KFAST ? (idx & (BK - 1)) : (idx >> 6);
-      int nn = B_KFAST ? (idx >> 5) : (idx & (BN - 1));
-      Bs[nn * LDT + kk] = rb[e];
-    }
-  };
+  TileLoader<AMODE> la;
+  TileLoader<BMODE> lb;
+  la.setup(tid, kbeg, g.segT);
+  lb.setup(tid, kbeg, g.segT);
 
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
 
-  const int arow = (wr * 32 + (lane & 31)) * LDT + (lane >> 5);
-  const int brow = (wc * 32 + (lane & 31)) * LDT + (lane >> 5);
+  const int aoff = (lane >> 5) * LDS_LD + wr * 32 + (lane & 31);
+  const int boff = (lane >> 5) * LDS_LD + wc * 32 + (lane & 31);
 
   if (kbeg < kend) {
-    gload(kbeg);
-    sstore();
+    la.load(g.A, g.sam, g.sak, g.a_seg, g.segT, false, m0, g.M, kbeg, kend);
+    lb.load(g.B, g.sbn, g.sbk, g.b_seg, g.segT, g.shift != 0, n0, g.N, kbeg, kend);
+    la.store(As); lb.store(Bs);
     __syncthreads();
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
       const bool more = (k0 + BK) < kend;
-      if (more) gload(k0 + BK);
+      if (more) {
+        la.load(g.A, g.sam, g.sak, g.a_seg, g.segT, false, m0, g.M, k0 + BK, kend);
+        lb.load(g.B, g.sbn, g.sbk, g.b_seg, g.segT, g.shift != 0, n0, g.N, k0 + BK, kend);
+      }
 #pragma unroll
       for (int kk = 0; kk < BK; kk += 2) {
-        float a = As[arow + kk];
-        float b = Bs[brow + kk];
+        float a = As[aoff + kk * LDS_LD];
+        float b = Bs[boff + kk * LDS_LD];
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
       }
       __syncthreads();
       if (more) {
-        sstore();
+        la.store(As); lb.store(Bs);
         __syncthreads();
       }
     }
   }
 
-  float* C = g.C + (long)blockIdx.z * g.slab;
+  float* C = g.C + (long)bz * g.slab;
   const int col = n0 + wc * 32 + (lane & 31);
   if (col < g.N) {
     const float bv = g.bias ? g.bias[col] : 0.0f;
@@ -134,6 +211,36 @@ __global__ __launch_bounds__(256) void s2g_k_gemm_f32(GemmArgs g) {
   }
 }
 
+template <int AMODE, int BMODE>
+__global__ __launch_bounds__(256) void s2g_k_gemm_f32(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float As[BK * LDS_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * LDS_LD];
+  gemm_tile<AMODE, BMODE>(g, blockIdx.x, blockIdx.y, blockIdx.z, As, Bs);
+}
+
+// Grouped launch: `table` holds nprob independent problems, all of the TN weight-gradient shape:
+// A = [rows, M] row-major with sam == 1, sak % 4 == 0 and a 16-byte aligned base (loaded with
+// float4 along m), B with arbitrary strides; problem p owns blocks [prefix[p], prefix[p+1]),
+// ordered (z, y, x) with x fastest.  One launch fills the chip with work that would otherwise be
+// a dozen small back-to-back launches.
+extern "C" __global__ __launch_bounds__(256) void s2g_k_gemm_grouped(const GemmArgs* __restrict__ table,
+                                                                     const int* __restrict__ prefix, int nprob) {
+  __shared__ __attribute__((aligned(16))) float As[BK * LDS_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * LDS_LD];
+  __shared__ GemmArgs gs;
+  __shared__ int local;
+  if (threadIdx.x == 0) {
+    int p = 0;
+    while (p + 1 < nprob && (int)blockIdx.x >= prefix[p + 1]) ++p;
+    gs = table[p];
+    local = blockIdx.x - prefix[p];
+  }
+  __syncthreads();
+  const int nx = (gs.N + BN - 1) / BN, ny = (gs.M + BM - 1) / BM;
+  const int bx = local % nx, by = (local / nx) % ny, bz = local / (nx * ny);
+  gemm_tile<1, 0>(gs, bx, by, bz, As, Bs);
+}
+
 // out[perm(r)][c] (+)= scale * sum_z slabs[z][r][c];   perm = internal gate row -> torch row when
 // permute_rows, identity otherwise.  One thread per output element.
 extern "C" __global__ void s2g_k_reduce_slabs(const float* __restrict__ slabs, long slab, int nslab,
@@ -142,8 +249,14 @@ extern "C" __global__ void s2g_k_reduce_slabs(const float* __restrict__ slabs, l
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)rows * cols) return;
   int r = (int)(i / cols), c = (int)(i % cols);
-  float s = 0.0f;
-  for (int z = 0; z < nslab; ++z) s += slabs[(long)z * slab + i];
+  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+  int z = 0;
+  for (; z + 4 <= nslab; z += 4) {
+    s0 += slabs[(long)z * slab + i]; s1 += slabs[(long)(z + 1) * slab + i];
+    s2 += slabs[(long)(z + 2) * slab + i]; s3 += slabs[(long)(z + 3) * slab + i];
+  }
+  for (; z < nslab; ++z) s0 += slabs[(long)z * slab + i];
+  float s = (s0 + s1) + (s2 + s3);
   int ro = permute_rows ? pt_row(r) : r;
   long o = (long)ro * cols + c;
   s *= scale;
@@ -177,10 +290,28 @@ extern "C" int s2g_launch_gemm(const GemmArgs* ga, int nsplit, hipStream_t strea
   if (g.kchunk <= 0) g.kchunk = ((g.K + nsplit - 1) / nsplit + BK - 1) / BK * BK;
   if (g.kchunk <= 0) g.kchunk = BK;
   dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, nsplit);
-  const bool ak = (g.sak == 1), bk = (g.sbk == 1);
-  if (ak && bk) hipLaunchKernelGGL((s2g_k_gemm_f32<true, true>), grid, dim3(256), 0, stream, g);
-  else if (ak) hipLaunchKernelGGL((s2g_k_gemm_f32<true, false>), grid, dim3(256), 0, stream, g);
-  else if (bk) hipLaunchKernelGGL((s2g_k_gemm_f32<false, true>), grid, dim3(256), 0, stream, g);
-  else hipLaunchKernelGGL((s2g_k_gemm_f32<false, false>), grid, dim3(256), 0, stream, g);
+  auto al16 = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
+  // operand load modes (see TileLoader): 1 = float4 along the non-k index, 2 = float4 along k, 0 = scalar
+  int am = 0, bm = 0;
+  if (g.sam == 1 && (g.sak % 4) == 0 && al16(g.A)) am = 1;
+  else if (g.sak == 1 && (g.sam % 4) == 0 && al16(g.A) && g.segT == 0 && (g.kchunk % 4) == 0) am = 2;
+  else if (g.sak == 1) am = 3;
+  if (g.sbn == 1 && (g.sbk % 4) == 0 && al16(g.B)) bm = 1;
+  else if (g.sbk == 1 && (g.sbn % 4) == 0 && al16(g.B) && g.segT == 0 && (g.kchunk % 4) == 0) bm = 2;
+  else if (g.sbk == 1) bm = 3;
+#define S2G_GEMM_CASE(AM, BM_)                                                                     \
+  if (am == AM && bm == BM_) hipLaunchKernelGGL((s2g_k_gemm_f32<AM, BM_>), grid, dim3(256), 0, stream, g);
+  S2G_GEMM_CASE(0, 0) S2G_GEMM_CASE(0, 1) S2G_GEMM_CASE(0, 2)
+  S2G_GEMM_CASE(1, 0) S2G_GEMM_CASE(1, 1) S2G_GEMM_CASE(1, 2)
+  S2G_GEMM_CASE(2, 0) S2G_GEMM_CASE(2, 1) S2G_GEMM_CASE(2, 2)
+  S2G_GEMM_CASE(3, 0) S2G_GEMM_CASE(3, 1) S2G_GEMM_CASE(3, 2) S2G_GEMM_CASE(3, 3)
+  S2G_GEMM_CASE(0, 3) S2G_GEMM_CASE(1, 3) S2G_GEMM_CASE(2, 3)
+#undef S2G_GEMM_CASE
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int s2g_launch_gemm_grouped(const GemmArgs* table_dev, const int* prefix_dev, int nprob, int total_blocks,
+                                       hipStream_t stream) {
+  hipLaunchKernelGGL(s2g_k_gemm_grouped, dim3(total_blocks), dim3(256), 0, stream, table_dev, prefix_dev, nprob);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

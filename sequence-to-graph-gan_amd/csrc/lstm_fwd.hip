@@ -11,7 +11,10 @@
 // its 13-value slice of h from LDS (16-byte reads), reduces the 4 partial sums over the quad
 // with DPP, applies the gate nonlinearity of gate `s`, and the quad shares the four gates by
 // DPP broadcasts for the cell update.  Per-step inputs (input projection, dropout mask, saved
-// gates) are prefetched PF steps ahead into registers so no step waits on HBM.
+// gates) are prefetched PF steps ahead into a register ring.  Every prefetch is issued
+// UNCONDITIONALLY from a clamped address (lanes/steps that do not need the value read a valid
+// dummy location with stride 0): a load under a branch makes the compiler drain vmcnt to 0 at
+// the join, which would put a full memory round trip on every one of the 512 sequential steps.
 #include "s2g_common.h"
 
 #define PF 4
@@ -39,9 +42,17 @@ __device__ __forceinline__ void load_w_slice(const float* W, int u, int s, bool 
 #pragma unroll
     for (int j = 0; j < 13; ++j) {
       int k = 13 * s + j;
-      w[q][j] = (valid && k < S2G_H) ? W[(q * S2G_H + u) * S2G_H + k] : 0.0f;
+      bool ok = valid && k < S2G_H;
+      float v = W[(q * S2G_H + u) * S2G_H + (k < S2G_H ? k : S2G_H - 1)];
+      w[q][j] = ok ? v : 0.0f;
     }
 }
+
+#define FMA13(acc, w, v)                                                    \
+  _Pragma("unroll") for (int k_ = 0; k_ < 13; ++k_) {                      \
+    acc##0 = fmaf(w[0][k_], v[k_], acc##0); acc##1 = fmaf(w[1][k_], v[k_], acc##1); \
+    acc##2 = fmaf(w[2][k_], v[k_], acc##2); acc##3 = fmaf(w[3][k_], v[k_], acc##3); \
+  }
 
 // ------------------------------------------------------------------------------------------
 // Sweep A.  Saves per (row = ws_row + t): gates{0,1}[row][4u+q] = activated gate q of unit u;
@@ -70,12 +81,15 @@ extern "C" __global__ __launch_bounds__(512) void s2g_k_lstm2_fwd(
   const int uc = valid ? u : S2G_H - 1;
   const int len = sq.len;
   const bool has_tok = sq.tok_off >= 0 && sq.ca != 0.0f;
-  const bool has_p = sq.p_off >= 0 && sq.cp != 0.0f;
-  const bool has_mask = sq.mask_off >= 0;
+  const bool has_p = sq.p_off >= 0 && sq.cp != 0.0f && sq.p_len > 0;
+  const bool has_mask = sq.mask_off >= 0 && mask != nullptr;
 
+  if (len <= 0) {
+    if (grp == 1 && valid && s == 0) hT[(size_t)n * S2G_H + u] = 0.0f;
+    return;
+  }
   for (int i = tid; i < 384; i += 512) h0buf[i] = 0.0f;
-  if (has_tok)
-    for (int i = tid; i < len; i += 512) tok_lds[i] = tokens[sq.tok_off + i];
+  for (int i = tid; i < len; i += 512) tok_lds[i] = has_tok ? tokens[sq.tok_off + i] : 0;
 
   // per-lane activation constants: gate 2 (g) is tanh = 2*sigma(2x)-1, the others sigma
   const float ksc = (s == 2) ? -2.8853900817779268f : -1.4426950408889634f;
@@ -83,52 +97,61 @@ extern "C" __global__ __launch_bounds__(512) void s2g_k_lstm2_fwd(
   const float kb = (s == 2) ? -1.0f : 0.0f;
 
   float wA[4][13], wB[4][13];
+  const int col = 4 * uc + s;   // this lane's column in every [rows, 200] buffer
   float bias;
   if (grp == 0) {
     load_w_slice(whh0, uc, s, valid, wA);
-    bias = b0[4 * uc + s];
+    bias = b0[col];
   } else {
     load_w_slice(wih1, uc, s, valid, wA);
     load_w_slice(whh1, uc, s, valid, wB);
-    bias = b1[4 * uc + s];
+    bias = b1[col];
   }
   __syncthreads();
 
-  const int col = 4 * uc + s;   // this lane's column in every [rows, 200] buffer
+  // prefetch sources: real pointer + stride for lanes that need the value, (b0, 0) otherwise
+  const bool l0 = grp == 0;
+  const float* pa = (l0 && has_tok) ? WT0 + col : b0;
+  const int sa = (l0 && has_tok) ? S2G_G : 0;
+  const float* pp = (l0 && has_p) ? P + (size_t)sq.p_off * S2G_G + col : b0;
+  const int sp = (l0 && has_p) ? S2G_G : 0;
+  const float* pm = (l0 && has_mask) ? mask + (size_t)sq.mask_off * S2G_MASKW + uc : b0;
+  const int sm = (l0 && has_mask) ? S2G_MASKW : 0;
+  const float ca = has_tok ? sq.ca : 0.0f;
+  const float cp = has_p ? sq.cp : 0.0f;
+  const int plast = sq.p_len > 0 ? sq.p_len - 1 : 0;
+
   float xa[PF], xp[PF], mk[PF];
+#define ISSUE_A(j, t)                                                        \
+  {                                                                          \
+    int tc_ = min((t), len - 1);                                             \
+    xa[j] = pa[(size_t)tok_lds[tc_] * sa];                                   \
+    xp[j] = pp[(size_t)min(tc_, plast) * sp];                                \
+    mk[j] = pm[(size_t)tc_ * sm];                                            \
+  }
 #pragma unroll
-  for (int j = 0; j < PF; ++j) { xa[j] = 0.f; xp[j] = 0.f; mk[j] = 1.f; }
-  auto issue = [&](int j, int t) {
-    if (grp == 0 && t < len) {
-      if (has_tok) xa[j] = WT0[(size_t)tok_lds[t] * S2G_G + col];
-      if (has_p) xp[j] = (t < sq.p_len) ? P[(size_t)(sq.p_off + t) * S2G_G + col] : 0.0f;
-      if (has_mask) mk[j] = mask[(size_t)(sq.mask_off + t) * S2G_MASKW + uc];
-    }
-  };
-#pragma unroll
-  for (int j = 0; j < PF; ++j) issue(j, j);
+  for (int j = 0; j < PF; ++j) ISSUE_A(j, j)
 
   float c = 0.0f;
   for (int base = 0; base <= len; base += PF) {
 #pragma unroll
     for (int j = 0; j < PF; ++j) {
       const int tau = base + j;
+      // consume ring slot j (step tau) and refill it for step tau+PF, unconditionally
+      const float xa_c = xa[j], xp_c = xp[j], mk_c = mk[j];
+      ISSUE_A(j, tau + PF)
       if (tau <= len) {
         if (grp == 0) {
           if (tau < len) {
             const int t = tau;
-            float xv = sq.ca * xa[j] + sq.cp * xp[j] + bias;
-            float m = mk[j];
-            issue(j, t + PF);
+            float xv = fmaf(ca, xa_c, bias);
+            xv = fmaf((t < sq.p_len) ? cp : 0.0f, xp_c, xv);
+            const float m = has_mask ? mk_c : 1.0f;
             float hv[13];
             load_slice13(h0buf + ((t + 1) & 1) * 64, s, hv);
             float a0 = (s == 0) ? xv : 0.f, a1 = (s == 1) ? xv : 0.f, a2 = (s == 2) ? xv : 0.f,
                   a3 = (s == 3) ? xv : 0.f;
-#pragma unroll
-            for (int k = 0; k < 13; ++k) {
-              a0 = fmaf(wA[0][k], hv[k], a0); a1 = fmaf(wA[1][k], hv[k], a1);
-              a2 = fmaf(wA[2][k], hv[k], a2); a3 = fmaf(wA[3][k], hv[k], a3);
-            }
+            FMA13(a, wA, hv)
             a0 = quad_sum(a0); a1 = quad_sum(a1); a2 = quad_sum(a2); a3 = quad_sum(a3);
             float pre = sel4(s, a0, a1, a2, a3);
             float val = fmaf(ka, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(ksc * pre)), kb);
@@ -154,16 +177,8 @@ extern "C" __global__ __launch_bounds__(512) void s2g_k_lstm2_fwd(
             load_slice13(h1buf + ((t + 1) & 1) * 64, s, hv);
             float a0 = (s == 0) ? bias : 0.f, a1 = (s == 1) ? bias : 0.f, a2 = (s == 2) ? bias : 0.f,
                   a3 = (s == 3) ? bias : 0.f;
-#pragma unroll
-            for (int k = 0; k < 13; ++k) {
-              a0 = fmaf(wA[0][k], yv[k], a0); a1 = fmaf(wA[1][k], yv[k], a1);
-              a2 = fmaf(wA[2][k], yv[k], a2); a3 = fmaf(wA[3][k], yv[k], a3);
-            }
-#pragma unroll
-            for (int k = 0; k < 13; ++k) {
-              a0 = fmaf(wB[0][k], hv[k], a0); a1 = fmaf(wB[1][k], hv[k], a1);
-              a2 = fmaf(wB[2][k], hv[k], a2); a3 = fmaf(wB[3][k], hv[k], a3);
-            }
+            FMA13(a, wA, yv)
+            FMA13(a, wB, hv)
             a0 = quad_sum(a0); a1 = quad_sum(a1); a2 = quad_sum(a2); a3 = quad_sum(a3);
             float pre = sel4(s, a0, a1, a2, a3);
             float val = fmaf(ka, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(ksc * pre)), kb);
@@ -187,7 +202,6 @@ extern "C" __global__ __launch_bounds__(512) void s2g_k_lstm2_fwd(
       }
     }
   }
-  if (len == 0 && grp == 1 && valid && s == 0) hT[(size_t)n * S2G_H + u] = 0.0f;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -217,8 +231,12 @@ extern "C" __global__ __launch_bounds__(512) void s2g_k_lstm2_tangent(
   const bool valid = u < S2G_H;
   const int uc = valid ? u : S2G_H - 1;
   const int len = sq.len;
-  const bool has_mask = sq.mask_off >= 0;
+  const bool has_mask = sq.mask_off >= 0 && mask != nullptr;
 
+  if (len <= 0) {
+    if (grp == 1 && valid && s == 0) hdotT[(size_t)n * S2G_H + u] = 0.0f;
+    return;
+  }
   for (int i = tid; i < 384; i += 512) lds[i] = 0.0f;
 
   float wA[4][13], wB[4][13];
@@ -231,105 +249,91 @@ extern "C" __global__ __launch_bounds__(512) void s2g_k_lstm2_tangent(
   __syncthreads();
 
   const int col = 4 * uc + s;
-  const float* gates = grp == 0 ? gates0 : gates1;
-  const float* cell = grp == 0 ? cell0 : cell1;
-  // ring: xd (layer 0 only), gate value of (u, s), and one cell component per lane:
-  // lane s=0 fetches c_{t-1}, lane s=1 fetches tanh(c_t)
+  const bool l0 = grp == 0;
+  const size_t rbase = (size_t)sq.ws_row * S2G_G + col;
+  const float* pg = (l0 ? gates0 : gates1) + rbase;
+  // one cell component per lane: lane s=0 needs c_{t-1}, lane s=1 needs tanh(c_t); others unused
+  const float* pc = (l0 ? cell0 : cell1) + rbase;
+  const int cshift = (s == 0) ? 1 : 0;
+  const float* px = l0 ? Xdot + rbase : whh0;
+  const int sx = l0 ? S2G_G : 0;
+  const float* pm = (l0 && has_mask) ? mask + (size_t)sq.mask_off * S2G_MASKW + uc : whh0;
+  const int sm = (l0 && has_mask) ? S2G_MASKW : 0;
+
   float xd[PF], gv[PF], cv[PF], mk[PF];
+  // Layer 1 runs one step behind layer 0: at unrolled position tau both groups use ring slot
+  // tau % PF, which holds step (tau - toff) of the lane's own layer (toff = 0 / 1).
+  const int toff = grp;
+#define ISSUE_C(j, t)                                                        \
+  {                                                                          \
+    int tc_ = max(min((t), len - 1), 0);                                     \
+    gv[j] = pg[(size_t)tc_ * S2G_G];                                         \
+    cv[j] = pc[(size_t)max(tc_ - cshift, 0) * S2G_G];                        \
+    xd[j] = px[(size_t)tc_ * sx];                                            \
+    mk[j] = pm[(size_t)tc_ * sm];                                            \
+  }
 #pragma unroll
-  for (int j = 0; j < PF; ++j) { xd[j] = 0.f; gv[j] = 0.f; cv[j] = 0.f; mk[j] = 1.f; }
-  auto issue = [&](int j, int t) {
-    if (t < len) {
-      const size_t row = (size_t)(sq.ws_row + t) * S2G_G;
-      gv[j] = gates[row + col];
-      if (s == 0) cv[j] = (t > 0) ? cell[row - S2G_G + col] : 0.0f;
-      if (s == 1) cv[j] = cell[row + col];
-      if (grp == 0) {
-        xd[j] = Xdot[row + col];
-        if (has_mask) mk[j] = mask[(size_t)(sq.mask_off + t) * S2G_MASKW + uc];
-      }
-    }
-  };
-#pragma unroll
-  for (int j = 0; j < PF; ++j) issue(j, j);
+  for (int j = 0; j < PF; ++j) ISSUE_C(j, j - toff)
 
   float cd = 0.0f;   // cdot carried
-  // One step of this lane's layer, consuming ring slot jj (a compile-time constant at every
-  // call site after unrolling, so the ring stays in registers).
-  auto step = [&](const int jj, const int t) __attribute__((always_inline)) {
-    float g_s = gv[jj], c_s = cv[jj], m = mk[jj];
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    if (grp == 0) {
-      float xv = xd[jj];
-      a0 = (s == 0) ? xv : 0.f; a1 = (s == 1) ? xv : 0.f; a2 = (s == 2) ? xv : 0.f;
-      a3 = (s == 3) ? xv : 0.f;
-    }
-    issue(jj, t + PF);
-    if (grp == 0) {
-      float hv[13];
-      load_slice13(h0buf + ((t + 1) & 1) * 64, s, hv);
-#pragma unroll
-      for (int k = 0; k < 13; ++k) {
-        a0 = fmaf(wA[0][k], hv[k], a0); a1 = fmaf(wA[1][k], hv[k], a1);
-        a2 = fmaf(wA[2][k], hv[k], a2); a3 = fmaf(wA[3][k], hv[k], a3);
-      }
-    } else {
-      float hv[13], yv[13];
-      load_slice13(ybuf + (t & 1) * 64, s, yv);
-      load_slice13(h1buf + ((t + 1) & 1) * 64, s, hv);
-#pragma unroll
-      for (int k = 0; k < 13; ++k) {
-        a0 = fmaf(wA[0][k], yv[k], a0); a1 = fmaf(wA[1][k], yv[k], a1);
-        a2 = fmaf(wA[2][k], yv[k], a2); a3 = fmaf(wA[3][k], yv[k], a3);
-      }
-#pragma unroll
-      for (int k = 0; k < 13; ++k) {
-        a0 = fmaf(wB[0][k], hv[k], a0); a1 = fmaf(wB[1][k], hv[k], a1);
-        a2 = fmaf(wB[2][k], hv[k], a2); a3 = fmaf(wB[3][k], hv[k], a3);
-      }
-    }
-    a0 = quad_sum(a0); a1 = quad_sum(a1); a2 = quad_sum(a2); a3 = quad_sum(a3);
-    float ad = sel4(s, a0, a1, a2, a3);
-    float dsig = (s == 2) ? (1.0f - g_s * g_s) : g_s * (1.0f - g_s);
-    float gd_s = dsig * ad;                       // tangent of gate s
-    float gi = quad_bcast<0>(g_s), gf = quad_bcast<1>(g_s), gg = quad_bcast<2>(g_s),
-          go = quad_bcast<3>(g_s);
-    float di = quad_bcast<0>(gd_s), df = quad_bcast<1>(gd_s), dg = quad_bcast<2>(gd_s),
-          dO = quad_bcast<3>(gd_s);
-    float cprev = quad_bcast<0>(c_s), tc = quad_bcast<1>(c_s);
-    cd = df * cprev + gf * cd + di * gg + gi * dg;
-    float hd = dO * tc + go * (1.0f - tc * tc) * cd;
-    float yd = m * hd;
-    if (valid) {
-      const size_t row = (size_t)(sq.ws_row + t) * S2G_G;
-      if (grp == 0) {
-        adot0[row + col] = ad;
-        celld0[row + col] = sel4(s, cd, hd, yd, 0.0f);
-        if (s == 0) h0buf[(t & 1) * 64 + pos13(u)] = hd;
-        if (s == 1) ybuf[(t & 1) * 64 + pos13(u)] = yd;
-      } else {
-        adot1[row + col] = ad;
-        celld1[row + col] = sel4(s, cd, hd, 0.0f, 0.0f);
-        if (s == 0) {
-          h1buf[(t & 1) * 64 + pos13(u)] = hd;
-          if (t == len - 1) hdotT[(size_t)n * S2G_H + u] = hd;
-        }
-      }
-    }
-  };
   for (int base = 0; base <= len; base += PF) {
 #pragma unroll
     for (int j = 0; j < PF; ++j) {
       const int tau = base + j;
+      // consume ring slot j and refill it for position tau+PF, unconditionally
+      float g_s = gv[j], c_s = cv[j];
+      const float x_s = l0 ? xd[j] : 0.0f, m_s = mk[j];
+      ISSUE_C(j, tau + PF - toff)
       if (tau <= len) {
-        if (grp == 0) {
-          if (tau < len) step(j, tau);
-        } else {
-          if (tau >= 1) step((j + PF - 1) % PF, tau - 1);
+        const bool act = l0 ? (tau < len) : (tau >= 1);
+        if (act) {
+          const int t = l0 ? tau : tau - 1;
+          if (s == 0 && t == 0) c_s = 0.0f;        // c_{-1} = 0
+          const float m = has_mask ? m_s : 1.0f;
+          float a0 = (s == 0) ? x_s : 0.f, a1 = (s == 1) ? x_s : 0.f, a2 = (s == 2) ? x_s : 0.f,
+                a3 = (s == 3) ? x_s : 0.f;
+          if (l0) {
+            float hv[13];
+            load_slice13(h0buf + ((t + 1) & 1) * 64, s, hv);
+            FMA13(a, wA, hv)
+          } else {
+            float hv[13], yv[13];
+            load_slice13(ybuf + (t & 1) * 64, s, yv);
+            load_slice13(h1buf + ((t + 1) & 1) * 64, s, hv);
+            FMA13(a, wA, yv)
+            FMA13(a, wB, hv)
+          }
+          a0 = quad_sum(a0); a1 = quad_sum(a1); a2 = quad_sum(a2); a3 = quad_sum(a3);
+          float ad = sel4(s, a0, a1, a2, a3);
+          float dsig = (s == 2) ? (1.0f - g_s * g_s) : g_s * (1.0f - g_s);
+          float gd_s = dsig * ad;                       // tangent of gate s
+          float gi = quad_bcast<0>(g_s), gf = quad_bcast<1>(g_s), gg = quad_bcast<2>(g_s),
+                go = quad_bcast<3>(g_s);
+          float di = quad_bcast<0>(gd_s), df = quad_bcast<1>(gd_s), dg = quad_bcast<2>(gd_s),
+                dO = quad_bcast<3>(gd_s);
+          float cprev = quad_bcast<0>(c_s), tc = quad_bcast<1>(c_s);
+          cd = df * cprev + gf * cd + di * gg + gi * dg;
+          float hd = dO * tc + go * (1.0f - tc * tc) * cd;
+          float yd = m * hd;
+          if (valid) {
+            const size_t row = (size_t)(sq.ws_row + t) * S2G_G;
+            if (l0) {
+              adot0[row + col] = ad;
+              celld0[row + col] = sel4(s, cd, hd, yd, 0.0f);
+              if (s == 0) h0buf[(t & 1) * 64 + pos13(u)] = hd;
+              if (s == 1) ybuf[(t & 1) * 64 + pos13(u)] = yd;
+            } else {
+              adot1[row + col] = ad;
+              celld1[row + col] = sel4(s, cd, hd, 0.0f, 0.0f);
+              if (s == 0) {
+                h1buf[(t & 1) * 64 + pos13(u)] = hd;
+                if (t == len - 1) hdotT[(size_t)n * S2G_H + u] = hd;
+              }
+            }
+          }
         }
         __syncthreads();
       }
     }
   }
-  if (len == 0 && grp == 1 && valid && s == 0) hdotT[(size_t)n * S2G_H + u] = 0.0f;
 }

@@ -48,6 +48,11 @@ int s2g_gemm_f32(const GemmArgs* args, int nsplit, void* stream) {
   return s2g_launch_gemm(args, nsplit, ST(stream));
 }
 
+int s2g_gemm_grouped(const GemmArgs* table_dev, const int* prefix_dev, int nprob, int total_blocks, void* stream) {
+  if (!table_dev || !prefix_dev || nprob <= 0 || nprob > 64 || total_blocks <= 0) return -1;
+  return s2g_launch_gemm_grouped(table_dev, prefix_dev, nprob, total_blocks, ST(stream));
+}
+
 int s2g_reduce_slabs(const float* slabs, long slab, int nslab, int rows, int cols, float* out, int permute_rows,
                      int accumulate, float scale, void* stream) {
   if (!slabs || !out || nslab <= 0 || rows <= 0 || cols <= 0) return -1;

@@ -59,6 +59,7 @@ class CriticEngine:
         self.b1 = torch.empty(G4, device=device)
         self.scratch = ops.Scratch(device)
         self.timed_events = None      # list -> (start, end) HIP event pairs around the 3B-sequence forward sweep
+        self._gemm_tables = {}        # cached device-side problem tables of the grouped weight-gradient GEMM
         self._ws_key = None
         self.ws: Dict[str, torch.Tensor] = {}
 
@@ -189,22 +190,61 @@ def make_desc(entries, device) -> torch.Tensor:
 # writes the torch-layout gradient.
 # ---------------------------------------------------------------------------------------------
 def _wgrad(eng: "CriticEngine", out: torch.Tensor, N: int, terms) -> None:
-    """terms: (A_ptr, K, B_ptr, sbk, sbn, segT, a_seg, b_seg, shift); A is [rows,200] row-major."""
-    slab = G4 * N
-    plan = []
-    total = 0
-    for t in terms:
-        K = t[1]
-        if K <= 0:
-            continue
-        ns = max(1, min(64, K // 512))
-        plan.append((t, ns, total))
-        total += ns
-    slabs = eng.scratch.get(total * slab)
-    for (A, K, B, sbk, sbn, segT, a_seg, b_seg, shift), ns, s0 in plan:
-        ops.gemm_raw(A, 1, G4, B, sbk, sbn, ptr(slabs, s0 * slab), N, G4, N, K, nsplit=ns, slab=slab, segT=segT,
-                     a_seg=a_seg, b_seg=b_seg, shift=shift)
-    ops.reduce_slabs(slabs, slab, total, G4, N, out, permute_rows=True)
+    """One weight gradient.  terms: (A_ptr, K, B_ptr, sbk, sbn, segT, a_seg, b_seg, shift); A is
+    [rows,200] row-major."""
+    _wgrad_grouped(eng, [(out, N, terms)], "single")
+
+
+def _wgrad_grouped(eng: "CriticEngine", jobs, cache_key) -> None:
+    """jobs: list of (out tensor [200,N] torch layout, N, terms).  Every product of every job runs
+    in ONE grouped GEMM launch (split-K slabs), then one reduce per job.  The device-side problem
+    table is cached per `cache_key` and rebuilt only when a pointer or size changes."""
+    import ctypes
+    from .lib import S2GGemm
+    plan, sig = [], []
+    total_slabs, blocks = 0, 0
+    job_slabs = []
+    for out, N, terms in jobs:
+        slab = G4 * N
+        first = total_slabs
+        base_elems = sum(js[1] * js[2] for js in job_slabs)
+        off = 0
+        nsl = 0
+        for (A, K, B, sbk, sbn, segT, a_seg, b_seg, shift) in terms:
+            if K <= 0:
+                continue
+            ns = max(1, min(32, (K + 2048) // 4096))
+            kchunk = ((K + ns - 1) // ns + 31) // 32 * 32
+            tiles = ((N + 63) // 64) * ((G4 + 63) // 64)
+            plan.append((A, K, B, sbk, sbn, segT, a_seg, b_seg, shift, N, ns, kchunk, base_elems + off, slab, blocks))
+            sig.append((A, K, B, sbk, sbn, segT, a_seg, b_seg, shift, N))
+            blocks += tiles * ns
+            off += ns * slab
+            nsl += ns
+        job_slabs.append((out, nsl, slab, base_elems))
+        total_slabs += nsl
+    need = sum(js[1] * js[2] for js in job_slabs)
+    slabs = eng.scratch.get(need)
+    sig = (tuple(sig), slabs.data_ptr())
+    cache = eng._gemm_tables.get(cache_key)
+    if cache is None or cache[0] != sig:
+        arr = (S2GGemm * len(plan))()
+        prefix = []
+        for i, (A, K, B, sbk, sbn, segT, a_seg, b_seg, shift, N, ns, kchunk, soff, slab, b0) in enumerate(plan):
+            arr[i] = S2GGemm(A, 1, G4, B, sbk, sbn, ptr(slabs, soff), N, slab, None, G4, N, K, kchunk, segT, a_seg,
+                             b_seg, int(shift), 0, 0, 1.0)
+            prefix.append(b0)
+        prefix.append(blocks)
+        raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(eng.device)
+        pre = torch.tensor(prefix, dtype=torch.int32, device=eng.device)
+        cache = (sig, raw, pre, len(plan), blocks)
+        eng._gemm_tables[cache_key] = cache
+    _, raw, pre, nprob, nblocks = cache
+    call("s2g_gemm_grouped", ptr(raw), ptr(pre), nprob, nblocks, stream_ptr())
+    for out, nsl, slab, base in job_slabs:
+        if nsl:
+            N = slab // G4
+            call("s2g_reduce_slabs", ptr(slabs, base), slab, nsl, G4, N, ptr(out), 1, 0, 1.0, stream_ptr())
 
 
 def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Tensor, labels: torch.Tensor,
@@ -269,23 +309,24 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
     a0, a1, cd0, cd1 = ws["abar0"], ws["abar1"], ws["celld0"], ws["celld1"]
     oi = r_int * G4
     n12, n3 = 2 * B * Tw, B * Tw
-    _wgrad(eng, g["lstm.weight_ih_l0"], V, [
+    jobs = [(g["lstm.weight_ih_l0"], V, [
         (ptr(d0), B * T, ptr(ws["xreal"]), V, 1, T, Tw, T, False),
         (ptr(d0, B * Tw * G4), B * Tf, ptr(fake), V, 1, Tf, Tw, Tf, False),
         (ptr(a0), B * T, ptr(ws["xhat"]), V, 1, T, Tw, T, False),
-        (ptr(d0, oi), n3, ptr(ws["G"]), V, 1, 0, 0, 0, False)])
-    _wgrad(eng, g["lstm.weight_hh_l0"], H, [
+        (ptr(d0, oi), n3, ptr(ws["G"]), V, 1, 0, 0, 0, False)]),
+            (g["lstm.weight_hh_l0"], H, [
         (ptr(d0), n12, ptr(c0, 2), G4, 4, Tw, Tw, Tw, True),
         (ptr(a0), n3, ptr(c0, oi + 2), G4, 4, Tw, Tw, Tw, True),
-        (ptr(d0, oi), n3, ptr(cd0, 1), G4, 4, Tw, Tw, Tw, True)])
-    _wgrad(eng, g["lstm.weight_ih_l1"], H, [
+        (ptr(d0, oi), n3, ptr(cd0, 1), G4, 4, Tw, Tw, Tw, True)]),
+            (g["lstm.weight_ih_l1"], H, [
         (ptr(d1), n12, ptr(c0, 3), G4, 4, 0, 0, 0, False),
         (ptr(a1), n3, ptr(c0, oi + 3), G4, 4, 0, 0, 0, False),
-        (ptr(d1, oi), n3, ptr(cd0, 2), G4, 4, 0, 0, 0, False)])
-    _wgrad(eng, g["lstm.weight_hh_l1"], H, [
+        (ptr(d1, oi), n3, ptr(cd0, 2), G4, 4, 0, 0, 0, False)]),
+            (g["lstm.weight_hh_l1"], H, [
         (ptr(d1), n12, ptr(c1, 2), G4, 4, Tw, Tw, Tw, True),
         (ptr(a1), n3, ptr(c1, oi + 2), G4, 4, Tw, Tw, Tw, True),
-        (ptr(d1, oi), n3, ptr(cd1, 1), G4, 4, Tw, Tw, Tw, True)])
+        (ptr(d1, oi), n3, ptr(cd1, 1), G4, 4, Tw, Tw, Tw, True)])]
+    _wgrad_grouped(eng, jobs, ("critic", B, T, Tf))
     sc = eng.scratch
     ops.colsum(d0, n12, G4, G4, g["lstm.bias_ih_l0"], sc, permute_rows=True)
     ops.colsum(a0, n3, G4, G4, g["lstm.bias_ih_l0"], sc, permute_rows=True, accumulate=True)

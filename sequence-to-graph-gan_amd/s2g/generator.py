@@ -76,7 +76,8 @@ class GeneratorEngine:
         return y, xhat, invstd
 
     def forward(self, z: torch.Tensor, labels: torch.Tensor, U: Optional[torch.Tensor], tau: float, hard: bool,
-                training: bool = True, save: bool = True, act: str = "gumbel_softmax") -> torch.Tensor:
+                training: bool = True, save: bool = True, act: str = "gumbel_softmax",
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
         ops._chk(z, name="noise")
         ops._chk(labels, torch.int64, "labels")
         B = z.shape[0]
@@ -103,7 +104,7 @@ class GeneratorEngine:
         if mode == 0 and U is None:
             U = torch.rand(B, self.L, self.V, device=dev)      # noise draw only; the sampler is the kernel
         y, y_soft = ops.gumbel_softmax_fwd(logits.view(B, self.L, self.V), U if mode == 0 else None, tau, mode,
-                                           hard)
+                                           hard, out=out)
         if save:
             self.saved = dict(z=z, labels=labels, x0=x0, a1=a1, a2=a2, xhat2=xhat2, inv2=inv2, a3=a3, xhat3=xhat3,
                               inv3=inv3, y_soft=y_soft, scale=(1.0 if mode == 2 else 1.0 / tau), B=B)

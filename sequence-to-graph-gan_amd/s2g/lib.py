@@ -35,6 +35,7 @@ SIGNATURES = {
     "s2g_gumbel_softmax_bwd": [P, P, P, L, I, F, P],
     "s2g_argmax_rows": [P, P, L, I, P],
     "s2g_gemm_f32": [ctypes.POINTER(S2GGemm), I, P],
+    "s2g_gemm_grouped": [P, P, I, I, P],
     "s2g_reduce_slabs": [P, L, I, I, I, P, I, I, F, P],
     "s2g_colsum": [P, L, L, I, P, L, P],
     "s2g_lstm2_fwd": [P, I, I] + [P] * 15,

@@ -130,7 +130,8 @@ MODES = {"gumbel_softmax": 0, "relaxed_bernoulli": 1}
 
 
 def gumbel_softmax_fwd(logits: torch.Tensor, U: Optional[torch.Tensor], tau: float, mode: int, hard: bool,
-                       bias: Optional[torch.Tensor] = None, bias_rows: int = 0):
+                       bias: Optional[torch.Tensor] = None, bias_rows: int = 0,
+                       out: Optional[torch.Tensor] = None):
     _chk(logits, name="logits")
     V = logits.shape[-1]
     rows = logits.numel() // V
@@ -138,7 +139,11 @@ def gumbel_softmax_fwd(logits: torch.Tensor, U: Optional[torch.Tensor], tau: flo
         _chk(U, name="U")
         if U.numel() != logits.numel():
             raise S2GError("gumbel_softmax: U must have the shape of logits")
-    y = torch.empty_like(logits)
+    if out is not None:
+        _chk(out, name="out")
+        if out.numel() != logits.numel():
+            raise S2GError("gumbel_softmax: out must have the size of logits")
+    y = out.view_as(logits) if out is not None else torch.empty_like(logits)
     y_soft = torch.empty_like(logits) if hard else None
     call("s2g_gumbel_softmax_fwd", ptr(logits), ptr(U), ptr(bias), bias_rows, ptr(y), ptr(y_soft), rows, V,
          float(tau), mode, int(hard), stream_ptr())

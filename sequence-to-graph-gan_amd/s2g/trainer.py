@@ -53,6 +53,7 @@ class WGANGPTrainer:
         self.mG, self.vG = self.mG_named.flat, self.vG_named.flat
         self.tD = 0
         self.tG = 0
+        self._fake = None
         self.last: Dict[str, torch.Tensor] = {}
 
     # ------------------------------------------------------------------ updates
@@ -74,7 +75,11 @@ class WGANGPTrainer:
             z = torch.randn(B, LATENT, device=dev)
         if alpha is None:
             alpha = torch.rand(B, device=dev)
-        fake = self.G.forward(z, labels, U, self.tau, self.hard, training=True, save=False)   # .detach(): no graph
+        # persistent output buffer: stable pointers let the grouped-GEMM problem table be reused
+        if self._fake is None or self._fake.shape[0] != B:
+            self._fake = torch.empty(B, self.L, self.V, device=dev)
+        fake = self.G.forward(z, labels, U, self.tau, self.hard, training=True, save=False,
+                              out=self._fake)                               # .detach(): no graph is kept
         Tw = max(T, self.L)
         if mask is None and self.drop_rate > 0.0:
             mask = dropout_mask(3 * B * Tw, self.drop_rate, dev)
