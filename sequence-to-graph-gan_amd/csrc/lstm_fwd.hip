@@ -3,203 +3,266 @@
 // states along an input direction, used by the gradient penalty's second-order term,
 // wgan_gp.py:247-256).
 //
-// Decomposition: ONE workgroup per sequence, both layers resident, exact fp32 on the VALU.
-//   waves 0-3: layer 0, step tau          lane = 4*unit + s, s = K-slice of 13 hidden inputs
-//   waves 4-7: layer 1, step tau-1        (layer 1 trails layer 0 by one step, so the two
-//                                          layers' steps overlap and one barrier per step suffices)
-// A lane keeps its 4 gate rows x 13 (26 for layer 1) recurrent weights in registers, fetches
-// its 13-value slice of h from LDS (16-byte reads), reduces the 4 partial sums over the quad
-// with DPP, applies the gate nonlinearity of gate `s`, and the quad shares the four gates by
-// DPP broadcasts for the cell update.  Per-step inputs (input projection, dropout mask, saved
-// gates) are prefetched PF steps ahead into a register ring.  Every prefetch is issued
-// UNCONDITIONALLY from a clamped address (lanes/steps that do not need the value read a valid
-// dummy location with stride 0): a load under a branch makes the compiler drain vmcnt to 0 at
-// the join, which would put a full memory round trip on every one of the 512 sequential steps.
+// A sweep is a chain of 512 dependent steps, so its time is (cycles per step) x 512.  A SIMD
+// issues one wave64 VALU instruction per 4 cycles whatever the number of resident waves, so the
+// design minimises VALU instructions per SIMD per step and spreads them evenly over the 4 SIMDs.
+// ONE workgroup of EIGHT waves per sequence; the three 200x50 mat-vecs of a step run
+// concurrently on different time steps, with a single barrier per step:
+//   waves 0,1  t = tau      a0 = xproj_t + W_hh0 h0_{t-1}  -> gates, c0, h0_t, y_t = mask*h0_t
+//   waves 4..7 t = tau-1    p1 = b1 + W_ih1 y_t             -> LDS
+//   waves 2,3  t = tau-2    a1 = p1 + W_hh1 h1_{t-1}        -> gates, c1, h1_t
+// (wave i sits on SIMD i%4: every SIMD gets one cell wave and one projection wave).
+// Cell waves: lane = (unit u, half s); it holds the 4 gate rows of u over columns 25s..25s+24 in
+// 100 registers, as packed pairs -> 50 v_pk_fma_f32 per step, the state slice coming from LDS in
+// 7 16-byte reads.  A 2-lane reduce-scatter (2 DPP adds) leaves gates (i,f) in lane s=0 and
+// (g,o) in lane s=1; each lane activates and stores its pair, lane 1 fetches (i,f) by DPP and
+// advances the cell.  Projection waves: lane = (unit, quarter s) with 13 columns, 26 v_pk_fma_f32
+// and a 4-lane reduce-scatter (3 DPP adds) that leaves gate s in lane s.
+// Per-step inputs are prefetched PF steps ahead into a register ring by UNCONDITIONAL loads from
+// clamped addresses (a load under a branch makes the compiler drain vmcnt to 0 at the join: one
+// full memory round trip on each of the 512 sequential steps).
 #include "s2g_common.h"
 
-#define PF 4
+#define PF 6
+#define FWD_THREADS 512
+#define HV 56                  // LDS state vector: 2 slices of 25 units, each padded to 28 floats
+#define FWD_LDS_FLOATS 864     // h0buf[2][HV] h1buf[2][HV] ybuf[2][64] p1buf[2][256]
 
-__device__ __forceinline__ void load_slice13(const float* buf, int s, float hv[13]) {
-  const float4* p = reinterpret_cast<const float4*>(buf + 16 * s);
-  float4 a = p[0], b = p[1], c = p[2];
-  float d = buf[16 * s + 12];
-  hv[0] = a.x; hv[1] = a.y; hv[2] = a.z; hv[3] = a.w;
-  hv[4] = b.x; hv[5] = b.y; hv[6] = b.z; hv[7] = b.w;
-  hv[8] = c.x; hv[9] = c.y; hv[10] = c.z; hv[11] = c.w;
-  hv[12] = d;
-}
+__device__ __forceinline__ int pos25(int k) { return 28 * (k / 25) + (k % 25); }
 
-__device__ __forceinline__ float sel4(int s, float a0, float a1, float a2, float a3) {
-  float lo = (s & 1) ? a1 : a0;
-  float hi = (s & 1) ? a3 : a2;
-  return (s & 2) ? hi : lo;
-}
-
-// Loads the 4 gate rows (torch layout rows q*H+u) x 13-column slice `s` of a [4H, H] matrix.
-__device__ __forceinline__ void load_w_slice(const float* W, int u, int s, bool valid, float w[4][13]) {
+// Cell-wave weights of lane (u, s): columns 25s..25s+24 of unit u's gate rows in a torch-layout
+// [4H, H] matrix.  wk = the gate pair this lane keeps (2s, 2s+1), wx = the pair it hands over.
+__device__ __forceinline__ void load_w_half(const float* W, int u, int s, f2 wk[25], f2 wx[25]) {
+  const int qk = 2 * s, qx = 2 * (s ^ 1);
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int j = 0; j < 13; ++j) {
-      int k = 13 * s + j;
-      bool ok = valid && k < S2G_H;
-      float v = W[(q * S2G_H + u) * S2G_H + (k < S2G_H ? k : S2G_H - 1)];
-      w[q][j] = ok ? v : 0.0f;
-    }
-}
-
-#define FMA13(acc, w, v)                                                    \
-  _Pragma("unroll") for (int k_ = 0; k_ < 13; ++k_) {                      \
-    acc##0 = fmaf(w[0][k_], v[k_], acc##0); acc##1 = fmaf(w[1][k_], v[k_], acc##1); \
-    acc##2 = fmaf(w[2][k_], v[k_], acc##2); acc##3 = fmaf(w[3][k_], v[k_], acc##3); \
+  for (int k = 0; k < 25; ++k) {
+    const int col = 25 * s + k;
+    wk[k] = (f2){W[((qk + 0) * S2G_H + u) * S2G_H + col], W[((qk + 1) * S2G_H + u) * S2G_H + col]};
+    wx[k] = (f2){W[((qx + 0) * S2G_H + u) * S2G_H + col], W[((qx + 1) * S2G_H + u) * S2G_H + col]};
   }
+}
+
+// pre-activations of gates (2s, 2s+1) of unit u = init + W . v; slice = this lane's 28-float slice
+__device__ __forceinline__ f2 matvec_half(const f2 wk[25], const f2 wx[25], const float* slice, f2 init) {
+  float v[28];
+  const float4* p = reinterpret_cast<const float4*>(slice);
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const float4 a = p[i];
+    v[4 * i] = a.x; v[4 * i + 1] = a.y; v[4 * i + 2] = a.z; v[4 * i + 3] = a.w;
+  }
+  f2 ak = init, ax = {0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 25; ++k) {
+    const f2 vv = {v[k], v[k]};
+    ak = __builtin_elementwise_fma(wk[k], vv, ak);
+    ax = __builtin_elementwise_fma(wx[k], vv, ax);
+  }
+  ak.x += dpp_mov<DPP_QUAD(1, 0, 3, 2)>(ax.x);
+  ak.y += dpp_mov<DPP_QUAD(1, 0, 3, 2)>(ax.y);
+  return ak;
+}
+
+// Projection-wave weights of lane (u, s): columns 13s..13s+12, slot q = gate (s ^ q)
+__device__ __forceinline__ void load_w_quarter(const float* W, int u, int s, f2 w01[13], f2 w23[13]) {
+#pragma unroll
+  for (int k = 0; k < 13; ++k) {
+    const int col = 13 * s + k;
+    const bool ok = col < S2G_H;
+    const int cc = ok ? col : 0;
+    float v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float x = W[((s ^ q) * S2G_H + u) * S2G_H + cc];
+      v[q] = ok ? x : 0.0f;
+    }
+    w01[k] = (f2){v[0], v[1]};
+    w23[k] = (f2){v[2], v[3]};
+  }
+}
+
+// gate s of unit u: (W . v) summed over the quad; slice = this lane's 16-float slice (pos13 layout)
+__device__ __forceinline__ float matvec_quarter(const f2 w01[13], const f2 w23[13], const float* slice) {
+  float v[16];
+  const float4* p = reinterpret_cast<const float4*>(slice);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float4 a = p[i];
+    v[4 * i] = a.x; v[4 * i + 1] = a.y; v[4 * i + 2] = a.z; v[4 * i + 3] = a.w;
+  }
+  f2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 13; ++k) {
+    const f2 vv = {v[k], v[k]};
+    a01 = __builtin_elementwise_fma(w01[k], vv, a01);
+    a23 = __builtin_elementwise_fma(w23[k], vv, a23);
+  }
+  return quad_reduce_scatter(a01.x, a01.y, a23.x, a23.y);
+}
+
+// value of the even lane of each lane pair
+__device__ __forceinline__ float from_even(float v) { return dpp_mov<DPP_QUAD(0, 0, 2, 2)>(v); }
 
 // ------------------------------------------------------------------------------------------
 // Sweep A.  Saves per (row = ws_row + t): gates{0,1}[row][4u+q] = activated gate q of unit u;
 // cell0[row][4u+{0,1,2,3}] = (c, tanh c, h, mask*h); cell1 likewise with the 4th slot 0;
 // hT[n][u] = final hidden state of layer 1.
+// Dynamic LDS: FWD_LDS_FLOATS floats + max_len ints.
 // ------------------------------------------------------------------------------------------
-extern "C" __global__ __launch_bounds__(512) void s2g_k_lstm2_fwd(
+extern "C" __global__ __launch_bounds__(FWD_THREADS) void s2g_k_lstm2_fwd(
     const S2GSeq* __restrict__ seqs, const int* __restrict__ tokens, const float* __restrict__ WT0,
     const float* __restrict__ P, const float* __restrict__ mask, const float* __restrict__ b0,
     const float* __restrict__ b1, const float* __restrict__ whh0, const float* __restrict__ wih1,
     const float* __restrict__ whh1, float* __restrict__ gates0, float* __restrict__ cell0,
     float* __restrict__ gates1, float* __restrict__ cell1, float* __restrict__ hT) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* h0buf = reinterpret_cast<float*>(smem);   // [2][64]
-  float* ybuf = h0buf + 128;                        // [2][64]
-  float* h1buf = ybuf + 128;                        // [2][64]
-  int* tok_lds = reinterpret_cast<int*>(h1buf + 128);
+  float* h0buf = reinterpret_cast<float*>(smem);   // [2][HV]
+  float* h1buf = h0buf + 2 * HV;                    // [2][HV]
+  float* ybuf = h1buf + 2 * HV;                     // [2][64], pos13 layout
+  float* p1buf = ybuf + 128;                        // [2][256]
+  int* tok_lds = reinterpret_cast<int*>(p1buf + 512);
 
   const int n = blockIdx.x;
   const S2GSeq sq = seqs[n];
   const int tid = threadIdx.x;
-  const int grp = tid >> 8;            // 0: layer 0, 1: layer 1 (wave-uniform)
-  const int l = tid & 255;
-  const int u = l >> 2, s = l & 3;
-  const bool valid = u < S2G_H;
-  const int uc = valid ? u : S2G_H - 1;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: role tests and row pointers stay scalar
+  const int lane = tid & 63;
   const int len = sq.len;
   const bool has_tok = sq.tok_off >= 0 && sq.ca != 0.0f;
   const bool has_p = sq.p_off >= 0 && sq.cp != 0.0f && sq.p_len > 0;
   const bool has_mask = sq.mask_off >= 0 && mask != nullptr;
 
   if (len <= 0) {
-    if (grp == 1 && valid && s == 0) hT[(size_t)n * S2G_H + u] = 0.0f;
+    if (tid < S2G_H) hT[(size_t)n * S2G_H + tid] = 0.0f;
     return;
   }
-  for (int i = tid; i < 384; i += 512) h0buf[i] = 0.0f;
-  for (int i = tid; i < len; i += 512) tok_lds[i] = has_tok ? tokens[sq.tok_off + i] : 0;
+  for (int i = tid; i < FWD_LDS_FLOATS; i += FWD_THREADS) h0buf[i] = 0.0f;
+  for (int i = tid; i < len; i += FWD_THREADS) tok_lds[i] = has_tok ? tokens[sq.tok_off + i] : 0;
+  const int nit = len + 2;                    // pipeline iterations (= barriers) of every wave
 
-  // per-lane activation constants: gate 2 (g) is tanh = 2*sigma(2x)-1, the others sigma
-  const float ksc = (s == 2) ? -2.8853900817779268f : -1.4426950408889634f;
-  const float ka = (s == 2) ? 2.0f : 1.0f;
-  const float kb = (s == 2) ? -1.0f : 0.0f;
-
-  float wA[4][13], wB[4][13];
-  const int col = 4 * uc + s;   // this lane's column in every [rows, 200] buffer
-  float bias;
-  if (grp == 0) {
-    load_w_slice(whh0, uc, s, valid, wA);
-    bias = b0[col];
-  } else {
-    load_w_slice(wih1, uc, s, valid, wA);
-    load_w_slice(whh1, uc, s, valid, wB);
-    bias = b1[col];
-  }
-  __syncthreads();
-
-  // prefetch sources: real pointer + stride for lanes that need the value, (b0, 0) otherwise
-  const bool l0 = grp == 0;
-  const float* pa = (l0 && has_tok) ? WT0 + col : b0;
-  const int sa = (l0 && has_tok) ? S2G_G : 0;
-  const float* pp = (l0 && has_p) ? P + (size_t)sq.p_off * S2G_G + col : b0;
-  const int sp = (l0 && has_p) ? S2G_G : 0;
-  const float* pm = (l0 && has_mask) ? mask + (size_t)sq.mask_off * S2G_MASKW + uc : b0;
-  const int sm = (l0 && has_mask) ? S2G_MASKW : 0;
-  const float ca = has_tok ? sq.ca : 0.0f;
-  const float cp = has_p ? sq.cp : 0.0f;
-  const int plast = sq.p_len > 0 ? sq.p_len - 1 : 0;
-
-  float xa[PF], xp[PF], mk[PF];
-#define ISSUE_A(j, t)                                                        \
-  {                                                                          \
-    int tc_ = min((t), len - 1);                                             \
-    xa[j] = pa[(size_t)tok_lds[tc_] * sa];                                   \
-    xp[j] = pp[(size_t)min(tc_, plast) * sp];                                \
-    mk[j] = pm[(size_t)tc_ * sm];                                            \
-  }
-#pragma unroll
-  for (int j = 0; j < PF; ++j) ISSUE_A(j, j)
-
-  float c = 0.0f;
-  for (int base = 0; base <= len; base += PF) {
-#pragma unroll
-    for (int j = 0; j < PF; ++j) {
-      const int tau = base + j;
-      // consume ring slot j (step tau) and refill it for step tau+PF, unconditionally
-      const float xa_c = xa[j], xp_c = xp[j], mk_c = mk[j];
-      ISSUE_A(j, tau + PF)
-      if (tau <= len) {
-        if (grp == 0) {
-          if (tau < len) {
-            const int t = tau;
-            float xv = fmaf(ca, xa_c, bias);
-            xv = fmaf((t < sq.p_len) ? cp : 0.0f, xp_c, xv);
-            const float m = has_mask ? mk_c : 1.0f;
-            float hv[13];
-            load_slice13(h0buf + ((t + 1) & 1) * 64, s, hv);
-            float a0 = (s == 0) ? xv : 0.f, a1 = (s == 1) ? xv : 0.f, a2 = (s == 2) ? xv : 0.f,
-                  a3 = (s == 3) ? xv : 0.f;
-            FMA13(a, wA, hv)
-            a0 = quad_sum(a0); a1 = quad_sum(a1); a2 = quad_sum(a2); a3 = quad_sum(a3);
-            float pre = sel4(s, a0, a1, a2, a3);
-            float val = fmaf(ka, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(ksc * pre)), kb);
-            float gi = quad_bcast<0>(val), gf = quad_bcast<1>(val), gg = quad_bcast<2>(val),
-                  go = quad_bcast<3>(val);
-            c = fmaf(gf, c, gi * gg);
-            float tc = fast_tanh(c);
-            float h = go * tc;
-            float y = m * h;
-            if (valid) {
-              const size_t row = (size_t)(sq.ws_row + t) * S2G_G;
-              gates0[row + col] = val;
-              cell0[row + col] = sel4(s, c, tc, h, y);
-              if (s == 0) h0buf[(t & 1) * 64 + pos13(u)] = h;
-              if (s == 1) ybuf[(t & 1) * 64 + pos13(u)] = y;
-            }
-          }
-        } else {
-          if (tau >= 1) {
-            const int t = tau - 1;
-            float hv[13], yv[13];
-            load_slice13(ybuf + (t & 1) * 64, s, yv);
-            load_slice13(h1buf + ((t + 1) & 1) * 64, s, hv);
-            float a0 = (s == 0) ? bias : 0.f, a1 = (s == 1) ? bias : 0.f, a2 = (s == 2) ? bias : 0.f,
-                  a3 = (s == 3) ? bias : 0.f;
-            FMA13(a, wA, yv)
-            FMA13(a, wB, hv)
-            a0 = quad_sum(a0); a1 = quad_sum(a1); a2 = quad_sum(a2); a3 = quad_sum(a3);
-            float pre = sel4(s, a0, a1, a2, a3);
-            float val = fmaf(ka, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(ksc * pre)), kb);
-            float gi = quad_bcast<0>(val), gf = quad_bcast<1>(val), gg = quad_bcast<2>(val),
-                  go = quad_bcast<3>(val);
-            c = fmaf(gf, c, gi * gg);
-            float tc = fast_tanh(c);
-            float h = go * tc;
-            if (valid) {
-              const size_t row = (size_t)(sq.ws_row + t) * S2G_G;
-              gates1[row + col] = val;
-              cell1[row + col] = sel4(s, c, tc, h, 0.0f);
-              if (s == 0) {
-                h1buf[(t & 1) * 64 + pos13(u)] = h;
-                if (t == len - 1) hT[(size_t)n * S2G_H + u] = h;
-              }
-            }
-          }
-        }
-        __syncthreads();
+  if (wv >= 4) {
+    // ---------------- projection waves: p1 = b1 + W_ih1 y_{tau-1} ----------------
+    const int u = 16 * (wv - 4) + (lane >> 2), s = lane & 3;
+    const bool valid = u < S2G_H;
+    const int uc = valid ? u : S2G_H - 1;
+    f2 w01[13], w23[13];
+    load_w_quarter(wih1, uc, s, w01, w23);
+    const float bias = b1[4 * uc + s];
+    __syncthreads();
+    for (int tau = 0; tau < nit; ++tau) {
+      const int t = tau - 1;
+      if (t >= 0 && t < len) {
+        const float r = matvec_quarter(w01, w23, ybuf + (t & 1) * 64 + 16 * s) + bias;
+        if (valid) p1buf[(t & 1) * 256 + 4 * u + s] = r;
       }
+      __syncthreads();
+    }
+    return;
+  }
+
+  // ---------------- cell waves ----------------
+  // Global addresses are (wave-uniform row pointer) + (constant per-lane offset): the row pointer
+  // lives in scalar registers and the per-step address arithmetic costs no vector instructions.
+  const bool l0 = wv < 2;
+  const int u = 32 * (wv & 1) + (lane >> 1), s = lane & 1;
+  const bool valid = u < S2G_H;
+  const int uc = valid ? u : S2G_H - 1;
+  const bool owner = valid && s == 1;
+  f2 wk[25], wx[25];
+  load_w_half(l0 ? whh0 : whh1, uc, s, wk, wx);
+  const unsigned lo4 = 4 * uc, lo2 = 4 * uc + 2 * s;          // lane offsets inside a 200-float row
+  const size_t row0 = (size_t)sq.ws_row * S2G_G;
+  const float kact = s ? -2.8853900817779268f : -1.4426950408889634f;   // lane 1's first gate is the tanh one
+  const float actA = s ? 2.0f : 1.0f, actB = s ? -1.0f : 0.0f;
+  const int hp = pos25(uc), yp = pos13(uc);
+
+  if (l0) {
+    const float2 bias = *reinterpret_cast<const float2*>(b0 + lo2);
+    // absent inputs read b0 (always 200 valid floats) with stride 0 and coefficient 0
+    const float* pa = has_tok ? WT0 : b0;
+    const int sa = has_tok ? S2G_G : 0;
+    const float* pp = has_p ? P + (size_t)sq.p_off * S2G_G : b0;
+    const int sp = has_p ? S2G_G : 0;
+    const float* pm = has_mask ? mask + (size_t)sq.mask_off * S2G_MASKW : b0;
+    const int sm = has_mask ? S2G_MASKW : 0;
+    const float ca = has_tok ? sq.ca : 0.0f;
+    const float cp = has_p ? sq.cp : 0.0f;
+    const int plast = sq.p_len > 0 ? sq.p_len - 1 : 0;
+    float* gout = gates0 + row0;
+    float* cout = cell0 + row0;
+    __syncthreads();
+    float2 xa[PF], xp[PF];
+    float mk[PF];
+#define ISSUE_A(j, t, token)                                                                 \
+    {                                                                                        \
+      const int tc_ = min((t), len - 1);                                                     \
+      const int tok_ = __builtin_amdgcn_readfirstlane(token);                                \
+      xa[j] = *reinterpret_cast<const float2*>(pa + (unsigned)(tok_ * sa) + lo2);            \
+      xp[j] = *reinterpret_cast<const float2*>(pp + (unsigned)(min(tc_, plast) * sp) + lo2); \
+      mk[j] = (pm + (unsigned)(tc_ * sm))[uc];                                               \
+    }
+#pragma unroll
+    for (int j = 0; j < PF; ++j) ISSUE_A(j, j, tok_lds[min(j, len - 1)])
+    int tk = tok_lds[min(PF, len - 1)];      // token of the next step to prefetch, read one step early
+    float c = 0.0f;
+    for (int base = 0; base < nit; base += PF) {
+#pragma unroll
+      for (int j = 0; j < PF; ++j) {
+        const int t = base + j;
+        if (t < nit) {
+          if (t < len) {
+            const float cpt = (t < sq.p_len) ? cp : 0.0f;
+            const f2 x = {fmaf(cpt, xp[j].x, fmaf(ca, xa[j].x, bias.x)), fmaf(cpt, xp[j].y, fmaf(ca, xa[j].y, bias.y))};
+            const f2 a = matvec_half(wk, wx, h0buf + ((t + 1) & 1) * HV + 28 * s, x);
+            const float v0 = fmaf(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(kact * a.x)), actA, actB);
+            const float v1 = fast_sigmoid(a.y);
+            const float gi = from_even(v0), gf = from_even(v1);      // lane 1: (i, f); its own v0, v1 = (g, o)
+            c = fmaf(gf, c, gi * v0);
+            const float tc = fast_tanh(c);
+            const float h = v1 * tc;
+            const float y = has_mask ? mk[j] * h : h;
+            float* grow = gout + (unsigned)(t * S2G_G);
+            float* crow = cout + (unsigned)(t * S2G_G);
+            if (valid) *reinterpret_cast<float2*>(grow + lo2) = make_float2(v0, v1);
+            if (owner) {
+              *reinterpret_cast<float4*>(crow + lo4) = make_float4(c, tc, h, y);
+              h0buf[(t & 1) * HV + hp] = h;
+              ybuf[(t & 1) * 64 + yp] = y;
+            }
+          }
+          __syncthreads();
+        }
+        // the slot is refilled only after its last use, so it keeps its registers across iterations
+        ISSUE_A(j, t + PF, tk)
+        tk = tok_lds[min(t + PF + 1, len - 1)];
+      }
+    }
+  } else {
+    float* gout = gates1 + row0;
+    float* cout = cell1 + row0;
+    __syncthreads();
+    float c = 0.0f;
+    for (int tau = 0; tau < nit; ++tau) {
+      const int t = tau - 2;
+      if (t >= 0) {
+        const float2 pin = *reinterpret_cast<const float2*>(p1buf + (t & 1) * 256 + lo2);
+        const f2 a = matvec_half(wk, wx, h1buf + ((t + 1) & 1) * HV + 28 * s, (f2){pin.x, pin.y});
+        const float v0 = fmaf(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(kact * a.x)), actA, actB);
+        const float v1 = fast_sigmoid(a.y);
+        const float gi = from_even(v0), gf = from_even(v1);
+        c = fmaf(gf, c, gi * v0);
+        const float tc = fast_tanh(c);
+        const float h = v1 * tc;
+        float* grow = gout + (unsigned)(t * S2G_G);
+        float* crow = cout + (unsigned)(t * S2G_G);
+        if (valid) *reinterpret_cast<float2*>(grow + lo2) = make_float2(v0, v1);
+        if (owner) {
+          *reinterpret_cast<float4*>(crow + lo4) = make_float4(c, tc, h, 0.0f);
+          h1buf[(t & 1) * HV + hp] = h;
+          if (t == len - 1) hT[(size_t)n * S2G_H + u] = h;
+        }
+      }
+      __syncthreads();
     }
   }
 }
@@ -210,130 +273,130 @@ extern "C" __global__ __launch_bounds__(512) void s2g_k_lstm2_fwd(
 // hdot_t = odot tanh(c) + o (1 - tanh^2 c) cdot.  Saves adot{0,1}[row][4u+q],
 // celld0[row][4u+{0,1,2,3}] = (cdot, hdot, mask*hdot, 0), celld1 = (cdot, hdot, 0, 0), hdotT.
 // Xdot holds the projected input direction rows [ws_row + t][200] (no bias).
+// Same eight-wave pipeline as sweep A; the cell waves prefetch the saved primal gates / cell values.
 // ------------------------------------------------------------------------------------------
-extern "C" __global__ __launch_bounds__(512) void s2g_k_lstm2_tangent(
+extern "C" __global__ __launch_bounds__(FWD_THREADS) void s2g_k_lstm2_tangent(
     const S2GSeq* __restrict__ seqs, const float* __restrict__ Xdot, const float* __restrict__ mask,
     const float* __restrict__ whh0, const float* __restrict__ wih1, const float* __restrict__ whh1,
     const float* __restrict__ gates0, const float* __restrict__ cell0, const float* __restrict__ gates1,
     const float* __restrict__ cell1, float* __restrict__ adot0, float* __restrict__ celld0,
     float* __restrict__ adot1, float* __restrict__ celld1, float* __restrict__ hdotT) {
-  __shared__ __attribute__((aligned(16))) float lds[384];
-  float* h0buf = lds;          // hdot of layer 0 [2][64]
-  float* ybuf = lds + 128;     // mask * hdot0    [2][64]
-  float* h1buf = lds + 256;    // hdot of layer 1 [2][64]
+  __shared__ __attribute__((aligned(16))) float lds[FWD_LDS_FLOATS];
+  float* h0buf = lds;                 // hdot of layer 0 [2][HV]
+  float* h1buf = lds + 2 * HV;        // hdot of layer 1 [2][HV]
+  float* ybuf = h1buf + 2 * HV;       // mask * hdot0    [2][64], pos13 layout
+  float* p1buf = ybuf + 128;          // W_ih1 ydot      [2][256]
 
   const int n = blockIdx.x;
   const S2GSeq sq = seqs[n];
   const int tid = threadIdx.x;
-  const int grp = tid >> 8;
-  const int l = tid & 255;
-  const int u = l >> 2, s = l & 3;
-  const bool valid = u < S2G_H;
-  const int uc = valid ? u : S2G_H - 1;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
   const int len = sq.len;
   const bool has_mask = sq.mask_off >= 0 && mask != nullptr;
 
   if (len <= 0) {
-    if (grp == 1 && valid && s == 0) hdotT[(size_t)n * S2G_H + u] = 0.0f;
+    if (tid < S2G_H) hdotT[(size_t)n * S2G_H + tid] = 0.0f;
     return;
   }
-  for (int i = tid; i < 384; i += 512) lds[i] = 0.0f;
+  for (int i = tid; i < FWD_LDS_FLOATS; i += FWD_THREADS) lds[i] = 0.0f;
+  const int nit = len + 2;
 
-  float wA[4][13], wB[4][13];
-  if (grp == 0) {
-    load_w_slice(whh0, uc, s, valid, wA);
-  } else {
-    load_w_slice(wih1, uc, s, valid, wA);
-    load_w_slice(whh1, uc, s, valid, wB);
+  if (wv >= 4) {
+    const int u = 16 * (wv - 4) + (lane >> 2), s = lane & 3;
+    const bool valid = u < S2G_H;
+    const int uc = valid ? u : S2G_H - 1;
+    f2 w01[13], w23[13];
+    load_w_quarter(wih1, uc, s, w01, w23);
+    __syncthreads();
+    for (int tau = 0; tau < nit; ++tau) {
+      const int t = tau - 1;
+      if (t >= 0 && t < len) {
+        const float r = matvec_quarter(w01, w23, ybuf + (t & 1) * 64 + 16 * s);
+        if (valid) p1buf[(t & 1) * 256 + 4 * u + s] = r;
+      }
+      __syncthreads();
+    }
+    return;
   }
+
+  // cell waves: 0,1 = layer 0 (lag 0), 2,3 = layer 1 (lag 2); shared element-wise code
+  const bool l0 = wv < 2;
+  const int lag = l0 ? 0 : 2;
+  const int u = 32 * (wv & 1) + (lane >> 1), s = lane & 1;
+  const bool valid = u < S2G_H;
+  const int uc = valid ? u : S2G_H - 1;
+  const bool owner = valid && s == 1;
+  f2 wk[25], wx[25];
+  load_w_half(l0 ? whh0 : whh1, uc, s, wk, wx);
+  // wave-uniform row pointers + constant per-lane offsets (see sweep A)
+  const unsigned lo4 = 4 * uc, lo2 = 4 * uc + 2 * s;
+  const size_t row0 = (size_t)sq.ws_row * S2G_G;
+  const float* pg = (l0 ? gates0 : gates1) + row0;
+  const float* pc = (l0 ? cell0 : cell1) + row0;
+  const float* px = l0 ? Xdot + row0 : whh0;          // absent inputs read whh0 (2500 floats) with stride 0
+  const int sx = l0 ? S2G_G : 0;
+  const float* pm = (l0 && has_mask) ? mask + (size_t)sq.mask_off * S2G_MASKW : whh0;
+  const int sm = (l0 && has_mask) ? S2G_MASKW : 0;
+  float* adot = (l0 ? adot0 : adot1) + row0;
+  float* celld = (l0 ? celld0 : celld1) + row0;
+  float* hb = l0 ? h0buf : h1buf;
+  const int hp = pos25(uc), yp = pos13(uc);
   __syncthreads();
 
-  const int col = 4 * uc + s;
-  const bool l0 = grp == 0;
-  const size_t rbase = (size_t)sq.ws_row * S2G_G + col;
-  const float* pg = (l0 ? gates0 : gates1) + rbase;
-  // one cell component per lane: lane s=0 needs c_{t-1}, lane s=1 needs tanh(c_t); others unused
-  const float* pc = (l0 ? cell0 : cell1) + rbase;
-  const int cshift = (s == 0) ? 1 : 0;
-  const float* px = l0 ? Xdot + rbase : whh0;
-  const int sx = l0 ? S2G_G : 0;
-  const float* pm = (l0 && has_mask) ? mask + (size_t)sq.mask_off * S2G_MASKW + uc : whh0;
-  const int sm = (l0 && has_mask) ? S2G_MASKW : 0;
-
-  float xd[PF], gv[PF], cv[PF], mk[PF];
-  // Layer 1 runs one step behind layer 0: at unrolled position tau both groups use ring slot
-  // tau % PF, which holds step (tau - toff) of the lane's own layer (toff = 0 / 1).
-  const int toff = grp;
+  float4 rg[PF];
+  float2 rx[PF], rc[PF];
+  float mk[PF];
 #define ISSUE_C(j, t)                                                        \
   {                                                                          \
-    int tc_ = max(min((t), len - 1), 0);                                     \
-    gv[j] = pg[(size_t)tc_ * S2G_G];                                         \
-    cv[j] = pc[(size_t)max(tc_ - cshift, 0) * S2G_G];                        \
-    xd[j] = px[(size_t)tc_ * sx];                                            \
-    mk[j] = pm[(size_t)tc_ * sm];                                            \
+    const int tc_ = max(min((t), len - 1), 0);                               \
+    rg[j] = *reinterpret_cast<const float4*>(pg + (unsigned)(tc_ * S2G_G) + lo4);  \
+    rc[j] = *reinterpret_cast<const float2*>(pc + (unsigned)(tc_ * S2G_G) + lo4);  \
+    rx[j] = *reinterpret_cast<const float2*>(px + (unsigned)(tc_ * sx) + lo2);     \
+    mk[j] = (pm + (unsigned)(tc_ * sm))[uc];                                       \
   }
+  // ring slot tau % PF holds step tau - lag
 #pragma unroll
-  for (int j = 0; j < PF; ++j) ISSUE_C(j, j - toff)
+  for (int j = 0; j < PF; ++j) ISSUE_C(j, j - lag)
 
-  float cd = 0.0f;   // cdot carried
-  for (int base = 0; base <= len; base += PF) {
+  float cd = 0.0f;      // cdot carried
+  float cprev = 0.0f;   // primal c_{t-1} carried
+  for (int base = 0; base < nit; base += PF) {
 #pragma unroll
     for (int j = 0; j < PF; ++j) {
       const int tau = base + j;
-      // consume ring slot j and refill it for position tau+PF, unconditionally
-      float g_s = gv[j], c_s = cv[j];
-      const float x_s = l0 ? xd[j] : 0.0f, m_s = mk[j];
-      ISSUE_C(j, tau + PF - toff)
-      if (tau <= len) {
-        const bool act = l0 ? (tau < len) : (tau >= 1);
-        if (act) {
-          const int t = l0 ? tau : tau - 1;
-          if (s == 0 && t == 0) c_s = 0.0f;        // c_{-1} = 0
-          const float m = has_mask ? m_s : 1.0f;
-          float a0 = (s == 0) ? x_s : 0.f, a1 = (s == 1) ? x_s : 0.f, a2 = (s == 2) ? x_s : 0.f,
-                a3 = (s == 3) ? x_s : 0.f;
-          if (l0) {
-            float hv[13];
-            load_slice13(h0buf + ((t + 1) & 1) * 64, s, hv);
-            FMA13(a, wA, hv)
-          } else {
-            float hv[13], yv[13];
-            load_slice13(ybuf + (t & 1) * 64, s, yv);
-            load_slice13(h1buf + ((t + 1) & 1) * 64, s, hv);
-            FMA13(a, wA, yv)
-            FMA13(a, wB, hv)
+      if (tau < nit) {
+        const int t = tau - lag;
+        if (t >= 0 && t < len) {
+          f2 init;
+          if (l0) init = (f2){rx[j].x, rx[j].y};
+          else {
+            const float2 pin = *reinterpret_cast<const float2*>(p1buf + (t & 1) * 256 + lo2);
+            init = (f2){pin.x, pin.y};
           }
-          a0 = quad_sum(a0); a1 = quad_sum(a1); a2 = quad_sum(a2); a3 = quad_sum(a3);
-          float ad = sel4(s, a0, a1, a2, a3);
-          float dsig = (s == 2) ? (1.0f - g_s * g_s) : g_s * (1.0f - g_s);
-          float gd_s = dsig * ad;                       // tangent of gate s
-          float gi = quad_bcast<0>(g_s), gf = quad_bcast<1>(g_s), gg = quad_bcast<2>(g_s),
-                go = quad_bcast<3>(g_s);
-          float di = quad_bcast<0>(gd_s), df = quad_bcast<1>(gd_s), dg = quad_bcast<2>(gd_s),
-                dO = quad_bcast<3>(gd_s);
-          float cprev = quad_bcast<0>(c_s), tc = quad_bcast<1>(c_s);
-          cd = df * cprev + gf * cd + di * gg + gi * dg;
-          float hd = dO * tc + go * (1.0f - tc * tc) * cd;
-          float yd = m * hd;
-          if (valid) {
-            const size_t row = (size_t)(sq.ws_row + t) * S2G_G;
-            if (l0) {
-              adot0[row + col] = ad;
-              celld0[row + col] = sel4(s, cd, hd, yd, 0.0f);
-              if (s == 0) h0buf[(t & 1) * 64 + pos13(u)] = hd;
-              if (s == 1) ybuf[(t & 1) * 64 + pos13(u)] = yd;
-            } else {
-              adot1[row + col] = ad;
-              celld1[row + col] = sel4(s, cd, hd, 0.0f, 0.0f);
-              if (s == 0) {
-                h1buf[(t & 1) * 64 + pos13(u)] = hd;
-                if (t == len - 1) hdotT[(size_t)n * S2G_H + u] = hd;
-              }
-            }
+          const f2 ad = matvec_half(wk, wx, hb + ((t + 1) & 1) * HV + 28 * s, init);
+          const float gi = rg[j].x, gf = rg[j].y, gg = rg[j].z, go = rg[j].w, tc = rc[j].y;
+          const float g0 = s ? gg : gi, g1 = s ? go : gf;              // this lane's gate pair
+          const float d0 = fmaf(-g0, g0, s ? 1.0f : g0) * ad.x;      // sigma' = g(1-g), tanh' = 1-g^2
+          const float d1 = fmaf(-g1, g1, g1) * ad.y;
+          const float di = from_even(d0), df = from_even(d1);          // lane 1: its own d0, d1 = (dg, do)
+          cd = df * cprev + gf * cd + di * gg + gi * d0;
+          cprev = rc[j].x;
+          const float hd = d1 * tc + go * (1.0f - tc * tc) * cd;
+          const float yd = (l0 && has_mask) ? mk[j] * hd : hd;
+          float* arow = adot + (unsigned)(t * S2G_G);
+          float* crow = celld + (unsigned)(t * S2G_G);
+          if (valid) *reinterpret_cast<float2*>(arow + lo2) = make_float2(ad.x, ad.y);
+          if (owner) {
+            *reinterpret_cast<float4*>(crow + lo4) = make_float4(cd, hd, l0 ? yd : 0.0f, 0.0f);
+            hb[(t & 1) * HV + hp] = hd;
+            if (l0) ybuf[(t & 1) * 64 + yp] = yd;
+            if (!l0 && t == len - 1) hdotT[(size_t)n * S2G_H + u] = hd;
           }
         }
         __syncthreads();
       }
+      ISSUE_C(j, tau + PF - lag)     // refill after the slot's last use: it keeps its registers
     }
   }
 }

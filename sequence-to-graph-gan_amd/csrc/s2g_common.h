@@ -46,6 +46,24 @@ __device__ __forceinline__ float row16_sum(float v) {
   v += dpp_mov<DPP_ROW_MIRROR>(v);
   return v;
 }
+// reduce-scatter over a quad.  Lane s (= lane & 3) holds four partial sums ordered so that slot q
+// belongs to item (s ^ q); on return lane s has the quad total of item s.  Three DPP adds and no
+// selects: at each butterfly stage the partner's "send" slot is exactly this lane's "keep" slot.
+__device__ __forceinline__ float quad_reduce_scatter(float s0, float s1, float s2, float s3) {
+  float r0 = s0 + dpp_mov<DPP_QUAD(1, 0, 3, 2)>(s1);
+  float r2 = s2 + dpp_mov<DPP_QUAD(1, 0, 3, 2)>(s3);
+  return r0 + dpp_mov<DPP_QUAD(2, 3, 0, 1)>(r2);
+}
+// sum of the 4 lanes {l, l^4, l^8, l^12} of a 16-lane DPP row (rotate-and-add); all 4 get the total
+#define DPP_ROW_ROR(n) (0x120 + (n))
+__device__ __forceinline__ float row_quads_sum(float v) {
+  v += dpp_mov<DPP_ROW_ROR(4)>(v);
+  v += dpp_mov<DPP_ROW_ROR(8)>(v);
+  return v;
+}
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
 template <int L>
 __device__ __forceinline__ float quad_bcast(float v) {
   return dpp_mov<DPP_QUAD(L, L, L, L)>(v);

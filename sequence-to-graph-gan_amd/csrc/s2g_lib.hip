@@ -75,8 +75,8 @@ int s2g_lstm2_fwd(const S2GSeq* seqs, int nseq, int max_len, const int* tokens, 
                   void* stream) {
   if (!seqs || nseq <= 0 || max_len < 0 || max_len > 16384) return -1;
   if (!b0 || !b1 || !whh0 || !wih1 || !whh1 || !gates0 || !cell0 || !gates1 || !cell1 || !hT) return -1;
-  size_t lds = 384 * sizeof(float) + (size_t)max_len * sizeof(int);
-  hipLaunchKernelGGL(s2g_k_lstm2_fwd, dim3(nseq), dim3(512), lds, ST(stream), seqs, tokens, WT0, P, mask, b0, b1,
+  size_t lds = FWD_LDS_FLOATS * sizeof(float) + (size_t)max_len * sizeof(int);
+  hipLaunchKernelGGL(s2g_k_lstm2_fwd, dim3(nseq), dim3(FWD_THREADS), lds, ST(stream), seqs, tokens, WT0, P, mask, b0, b1,
                      whh0, wih1, whh1, gates0, cell0, gates1, cell1, hT);
   return LAUNCH_OK();
 }
@@ -89,7 +89,7 @@ int s2g_lstm2_bwd(const S2GSeq* seqs, int nseq, int rows_per_seq, const float* m
   if (!whh0 || !wih1 || !whh1 || !gates0 || !cell0 || !gates1 || !cell1 || !dhT || !delta0 || !delta1) return -1;
   if ((adj0 == nullptr) != (adj1 == nullptr)) return -1;
   if (adj0 && (adj_seq0 < 0 || adj_row0 < 0)) return -1;
-  hipLaunchKernelGGL(s2g_k_lstm2_bwd, dim3(nseq), dim3(512), 0, ST(stream), seqs, mask, whh0, wih1, whh1, gates0,
+  hipLaunchKernelGGL(s2g_k_lstm2_bwd, dim3(nseq), dim3(BWD_THREADS), 0, ST(stream), seqs, mask, whh0, wih1, whh1, gates0,
                      cell0, gates1, cell1, dhT, delta0, delta1, adj0, adj1, rows_per_seq, adj_seq0, adj_row0);
   return LAUNCH_OK();
 }
@@ -101,7 +101,7 @@ int s2g_lstm2_tangent(const S2GSeq* seqs, int nseq, const float* Xdot, const flo
   if (!seqs || nseq <= 0 || !Xdot) return -1;
   if (!whh0 || !wih1 || !whh1 || !gates0 || !cell0 || !gates1 || !cell1) return -1;
   if (!adot0 || !celld0 || !adot1 || !celld1 || !hdotT) return -1;
-  hipLaunchKernelGGL(s2g_k_lstm2_tangent, dim3(nseq), dim3(512), 0, ST(stream), seqs, Xdot, mask, whh0, wih1,
+  hipLaunchKernelGGL(s2g_k_lstm2_tangent, dim3(nseq), dim3(FWD_THREADS), 0, ST(stream), seqs, Xdot, mask, whh0, wih1,
                      whh1, gates0, cell0, gates1, cell1, adot0, celld0, adot1, celld1, hdotT);
   return LAUNCH_OK();
 }
@@ -114,7 +114,7 @@ int s2g_lstm2_bwd2(const S2GSeq* seqs, int nseq, int rows_per_seq, const float* 
   if (!seqs || nseq <= 0 || rows_per_seq <= 0) return -1;
   if (!whh0 || !wih1 || !whh1 || !gates0 || !cell0 || !gates1 || !cell1) return -1;
   if (!adot0 || !celld0 || !adot1 || !celld1 || !adj0 || !adj1 || !abar0 || !abar1) return -1;
-  hipLaunchKernelGGL(s2g_k_lstm2_bwd2, dim3(nseq), dim3(512), 0, ST(stream), seqs, mask, whh0, wih1, whh1, gates0,
+  hipLaunchKernelGGL(s2g_k_lstm2_bwd2, dim3(nseq), dim3(BWD_THREADS), 0, ST(stream), seqs, mask, whh0, wih1, whh1, gates0,
                      cell0, gates1, cell1, adot0, celld0, adot1, celld1, adj0, adj1, abar0, abar1, rows_per_seq);
   return LAUNCH_OK();
 }

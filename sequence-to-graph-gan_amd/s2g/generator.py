@@ -116,15 +116,19 @@ class GeneratorEngine:
         sums = torch.empty(2 * F_, device=self.device)
         call("s2g_bn_lrelu_bwd_stats", ptr(a), ptr(da), ptr(xhat), ptr(sums), B, F_, stream_ptr())
         self.comm.allreduce(sums)
-        g[name + ".bias"].copy_(sums[:F_])
-        g[name + ".weight"].copy_(sums[F_:])
+        # sums are global already; the flat gradient bucket is SUM-reduced over ranks afterwards,
+        # so each rank contributes 1/world of them
+        share = 1.0 / float(self.comm.world)
+        torch.mul(sums[:F_], share, out=g[name + ".bias"])
+        torch.mul(sums[F_:], share, out=g[name + ".weight"])
         dpre = torch.empty_like(da)
         call("s2g_bn_bwd_apply", ptr(da), ptr(xhat), ptr(sums), float(B * self.comm.world),
              ptr(self.params.views[name + ".weight"]), ptr(inv), ptr(dpre), B, F_, stream_ptr())
         return dpre
 
     def backward(self, dy: torch.Tensor) -> None:
-        """Fills self.grads (local sums; BN gamma/beta gradients are already global) from d loss/d y."""
+        """Fills self.grads from d loss/d y with this rank's share: summing the buffer over ranks
+        gives the global gradient (BN gamma/beta enter as global/world)."""
         s = self.saved
         if not s:
             raise S2GError("generator.backward called without a saved forward")

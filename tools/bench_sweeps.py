@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Times the four LSTM sweeps in isolation (HIP events) at the north-star shape:
+A/B on 3*64 sequences, C/D on 64 sequences, 512 steps.  Development aid for kernel tuning."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "sequence-to-graph-gan_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+import torch  # noqa: E402
+
+import common  # noqa: E402
+from s2g.critic import CriticEngine, make_desc  # noqa: E402
+from s2g.ops import ptr  # noqa: E402
+
+
+def timeit(fn, reps=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
+def main():
+    dev = torch.device("cuda:0")
+    B, T, V = 64, 512, 175
+    for a in sys.argv[1:]:
+        if a.startswith("--T="):
+            T = int(a[4:])
+    use_mask = "--mask" in sys.argv
+    eng = CriticEngine(V, dev)
+    eng.load(common.critic_params(802))
+    ws = eng.workspace(3 * B, T, B)
+    P = torch.randn(B * T, 200, device=dev) * 0.3
+    tok = torch.randint(0, V, (B, T), device=dev, dtype=torch.int32)
+    mask = None
+    if use_mask:
+        mask = (torch.rand(3 * B * T, 52, device=dev) > 0.3).float() / 0.7
+    ent = []
+    for b in range(B):
+        ent.append(dict(len=T, tok_off=b * T, ca=1.0, cp=0.0, ws_row=b * T, mask_off=b * T if use_mask else -1))
+    for b in range(B):
+        ent.append(dict(len=T, p_off=b * T, p_len=T, ca=0.0, cp=1.0, ws_row=(B + b) * T,
+                        mask_off=(B + b) * T if use_mask else -1))
+    for b in range(B):
+        ent.append(dict(len=T, tok_off=b * T, p_off=b * T, p_len=T, ca=0.3, cp=0.7, ws_row=(2 * B + b) * T,
+                        mask_off=(2 * B + b) * T if use_mask else -1))
+    for b in range(B):
+        ent.append(dict(len=T, tok_off=b * T, p_off=b * T, p_len=T, ca=0.3, cp=0.7, ws_row=b * T,
+                        mask_off=b * T if use_mask else -1))
+    desc = make_desc(ent, dev)
+    ws["dhT"].normal_()
+    ws["Pv"].normal_()
+    r0 = 2 * B * T
+    mrel = ptr(mask, r0 * 52) if mask is not None else None
+    res = {}
+    res["fwd_192"] = timeit(lambda: eng.sweep_fwd(ws, ptr(desc), 3 * B, T, tok, P, mask))
+    res["fwd_64"] = timeit(lambda: eng.sweep_fwd(ws, ptr(desc), B, T, tok, P, mask))
+    res["bwd_192"] = timeit(lambda: eng.sweep_bwd(ws, ptr(desc), 3 * B, T, mask, adj_seq0=2 * B))
+    res["tangent_64"] = timeit(lambda: eng.sweep_tangent(ws, ptr(desc, 3 * B * 8), B, mrel, r0))
+    res["bwd2_64"] = timeit(lambda: eng.sweep_bwd2(ws, ptr(desc, 3 * B * 8), B, T, mrel, r0))
+    print(f"T={T} per-step ns:", " ".join(f"{k}={v * 1e3 / (T + 2):.0f}" for k, v in res.items()))
+    print(" ".join(f"{k}={v:.1f}us" for k, v in res.items()), f"sum4={res['fwd_192'] + res['bwd_192'] + res['tangent_64'] + res['bwd2_64']:.1f}us")
+
+
+if __name__ == "__main__":
+    main()
