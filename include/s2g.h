@@ -65,8 +65,9 @@ typedef struct S2GGemm {
 } S2GGemm;
 int s2g_gemm_f32(const S2GGemm* args, int nsplit, void* stream);
 /* nprob problems in ONE launch.  table_dev / prefix_dev are DEVICE arrays: S2GGemm[nprob] (every
- * problem with sak != 1 and sbk != 1, kchunk > 0 set by the caller) and int[nprob + 1] block
- * prefix sums; problem p owns ceil(N/64) * ceil(M/64) * nsplit_p blocks. */
+ * problem of the weight-gradient shape: A = [rows, M] with sam == 1, sak % 4 == 0 and a 16-byte
+ * aligned base, kchunk > 0 set by the caller, no bias / act / accumulate) and int[nprob + 1] block
+ * prefix sums; problem p owns ceil(N/64) * ceil(M/128) * nsplit_p blocks. */
 int s2g_gemm_grouped(const S2GGemm* table_dev, const int* prefix_dev, int nprob, int total_blocks, void* stream);
 int s2g_reduce_slabs(const float* slabs, long slab, int nslab, int rows, int cols, float* out,
                      int permute_rows, int accumulate, float scale, void* stream);

@@ -23,6 +23,19 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Operand pointers reach the kernels inside a struct (for the grouped launch, a struct read from
+// memory), where the compiler cannot prove they are global: it would emit flat loads, which also
+// count in lgkmcnt, so the first wait for an LDS read in the MFMA loop would also wait for every
+// prefetch in flight.  Loads go through explicit global-address-space pointers instead.
+typedef float nf4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) float* gfp;
+typedef const __attribute__((address_space(1))) nf4* gfp4;
+__device__ __forceinline__ float gload(const float* p) { return *(gfp)p; }
+__device__ __forceinline__ float4 gload4(const float* p) {
+  const nf4 v = *(gfp4)p;
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+
 struct GemmArgs {
   const float* A; long sam, sak;
   const float* B; long sbk, sbn;
@@ -41,7 +54,12 @@ struct SegPos {
   }
   __device__ __forceinline__ void advance(int dk, int segT) {
     t += dk;
-    if (segT > 0) while (t >= segT) { t -= segT; ++b; }
+    if (segT > 0) {
+      const bool wrap = t >= segT;             // the common single wrap stays a select, not a branch
+      t -= wrap ? segT : 0;
+      b += wrap ? 1 : 0;
+      if (t >= segT) { const int w = t / segT; b += w; t -= w * segT; }   // segments shorter than the stride
+    }
   }
 };
 
@@ -54,6 +72,7 @@ struct SegPos {
 template <int MODE>
 struct TileLoader {
   float r[8];
+  unsigned live;   // bit e: r[e] (MODE 0/3) or float4 e (MODE 1/2) is inside the matrix
   SegPos pos;      // position of this thread's first k of the current K-block
   int x, kq;       // x: non-k index inside the tile; kq: first k inside the K-block
 
@@ -66,25 +85,32 @@ struct TileLoader {
   }
   // P: base pointer; sx / sk: strides of the non-k / k index; seg: rows per sequence of this operand;
   // x0: tile origin; X: bound of the non-k index; shift: read step t-1, zero at t == 0.
+  // Every load is unconditional: an out-of-range element reads P[0] instead (offset selected, not
+  // branched) and is zeroed when the tile is written to LDS.  A load under a branch would force a
+  // wait for it at the join and expose the memory latency once per element.
   __device__ __forceinline__ void load(const float* P, long sx, long sk, int seg, int segT, bool shift, int x0,
                                        int X, int k0, int kend) {
     const int xi = x0 + x;
+    live = 0;
     if (MODE == 1) {
       SegPos q = pos;
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const int k = k0 + kq + 16 * e;
         long kr = segT > 0 ? (long)q.b * seg + q.t : (long)k;
-        bool ok = (xi + 3 < X) && (k < kend);
-        if (shift) { ok = ok && q.t != 0; kr -= 1; }
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) v = *reinterpret_cast<const float4*>(P + kr * sk + xi);
-        else if (xi < X && k < kend && !(shift && q.t == 0)) {     // ragged edge: element-wise
-          const float* src = P + kr * sk + xi;
-          v.x = src[0];
-          if (xi + 1 < X) v.y = src[1];
-          if (xi + 2 < X) v.z = src[2];
+        bool in = k < kend;
+        if (shift) { in = in && q.t != 0; kr -= 1; }
+        const bool full = in && (xi + 3 < X);
+        const float* src = P + kr * sk + xi;
+        float4 v = gload4(full ? src : P);
+        if (in && !full && xi < X) {       // ragged edge: element-wise (tiles on the matrix border only)
+          v.x = gload(src);
+          v.y = (xi + 1 < X) ? gload(src + 1) : 0.0f;
+          v.z = (xi + 2 < X) ? gload(src + 2) : 0.0f;
+          v.w = 0.0f;
+          live |= 1u << e;
         }
+        live |= full ? (1u << e) : 0u;
         r[4 * e] = v.x; r[4 * e + 1] = v.y; r[4 * e + 2] = v.z; r[4 * e + 3] = v.w;
         q.advance(16, segT);
       }
@@ -93,15 +119,16 @@ struct TileLoader {
       const float* src = P + (long)xi * sx + k;
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (xi < X) {
-          if (k + 4 * e + 3 < kend) v = *reinterpret_cast<const float4*>(src + 4 * e);
-          else {
-            if (k + 4 * e < kend) v.x = src[4 * e];
-            if (k + 4 * e + 1 < kend) v.y = src[4 * e + 1];
-            if (k + 4 * e + 2 < kend) v.z = src[4 * e + 2];
-          }
+        const bool full = (xi < X) && (k + 4 * e + 3 < kend);
+        float4 v = gload4(full ? src + 4 * e : P);
+        if (!full && xi < X && k + 4 * e < kend) {
+          v.x = gload(src + 4 * e);
+          v.y = (k + 4 * e + 1 < kend) ? gload(src + 4 * e + 1) : 0.0f;
+          v.z = (k + 4 * e + 2 < kend) ? gload(src + 4 * e + 2) : 0.0f;
+          v.w = 0.0f;
+          live |= 1u << e;
         }
+        live |= full ? (1u << e) : 0u;
         r[4 * e] = v.x; r[4 * e + 1] = v.y; r[4 * e + 2] = v.z; r[4 * e + 3] = v.w;
       }
     } else if (MODE == 3) {
@@ -112,7 +139,9 @@ struct TileLoader {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int xe = xi + 8 * e;
-        r[e] = (okk && xe < X) ? P[kr * sk + (long)xe * sx] : 0.0f;
+        const bool ok = okk && xe < X;
+        r[e] = gload(P + (ok ? kr * sk + (long)xe * sx : 0));
+        live |= ok ? (1u << e) : 0u;
       }
     } else {
       SegPos q = pos;
@@ -122,26 +151,35 @@ struct TileLoader {
         long kr = segT > 0 ? (long)q.b * seg + q.t : (long)k;
         bool ok = (xi < X) && (k < kend);
         if (shift) { ok = ok && q.t != 0; kr -= 1; }
-        r[e] = ok ? P[kr * sk + (long)xi * sx] : 0.0f;
+        r[e] = gload(P + (ok ? kr * sk + (long)xi * sx : 0));
+        live |= ok ? (1u << e) : 0u;
         q.advance(4, segT);
       }
     }
     pos.advance(BK, segT);
   }
+  __device__ __forceinline__ float val(int e) const { return (live >> e) & 1u ? r[e] : 0.0f; }
+  __device__ __forceinline__ float4 val4(int e) const {
+    return (live >> e) & 1u ? make_float4(r[4 * e], r[4 * e + 1], r[4 * e + 2], r[4 * e + 3])
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   __device__ __forceinline__ void store(float* S) const {
     if (MODE == 1) {
 #pragma unroll
-      for (int e = 0; e < 2; ++e)
-        *reinterpret_cast<float4*>(S + (kq + 16 * e) * LDS_LD + x) = make_float4(r[4 * e], r[4 * e + 1], r[4 * e + 2], r[4 * e + 3]);
+      for (int e = 0; e < 2; ++e) *reinterpret_cast<float4*>(S + (kq + 16 * e) * LDS_LD + x) = val4(e);
     } else if (MODE == 2) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) S[(kq + e) * LDS_LD + x] = r[e];
+      for (int e = 0; e < 2; ++e) {
+        const float4 v = val4(e);
+        S[(kq + 4 * e) * LDS_LD + x] = v.x; S[(kq + 4 * e + 1) * LDS_LD + x] = v.y;
+        S[(kq + 4 * e + 2) * LDS_LD + x] = v.z; S[(kq + 4 * e + 3) * LDS_LD + x] = v.w;
+      }
     } else if (MODE == 3) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) S[kq * LDS_LD + x + 8 * e] = r[e];
+      for (int e = 0; e < 8; ++e) S[kq * LDS_LD + x + 8 * e] = val(e);
     } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) S[(kq + 4 * e) * LDS_LD + x] = r[e];
+      for (int e = 0; e < 8; ++e) S[(kq + 4 * e) * LDS_LD + x] = val(e);
     }
   }
 };
@@ -218,27 +256,154 @@ __global__ __launch_bounds__(256) void s2g_k_gemm_f32(GemmArgs g) {
   gemm_tile<AMODE, BMODE>(g, blockIdx.x, blockIdx.y, blockIdx.z, As, Bs);
 }
 
+// Weight-gradient tile (TN shape, K = all saved rows): C[0:256, n0:n0+64] over one K-slab, M <= 256.
+// A = [rows, M] row-major with sam == 1 and M % 4 == 0, B generic strides.
+// Loader: wave w fetches rows k0 + w + 4e (e = 0..7) of both operands, one row per load
+// instruction with the lanes along m (float4) / n, so the row index -- and with it the whole
+// (sequence, step) bookkeeping of the segT mapping and the row address -- is wave-uniform and
+// lives in scalar registers; the vector unit only adds a constant lane offset.
+// MFMA: wave w owns rows [64w, 64w+64) x all 64 columns = four 32x32 accumulators; per k-pair it
+// reads 2 A and 2 B fragments for 4 MFMAs.
+#define WBM 256
+#define WLD_A 260   // k-major A tile [BK][256 + 4]
+__device__ __forceinline__ void wgrad_tile(const GemmArgs& g, const int bx, const int bz, float* As, float* Bs) {
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int n0 = bx * BN;
+  const int kbeg = bz * g.kchunk;
+  const int kend = min(g.K, kbeg + g.kchunk);
+  const int segT = g.segT;
+
+  // lane-constant parts
+  const bool a_in = 4 * lane + 3 < g.M;
+  const unsigned a_lane = a_in ? 4 * lane : 0;
+  const int ncol = n0 + lane;
+  const bool b_in = ncol < g.N;
+  const long b_lane = b_in ? (long)ncol * g.sbn : 0;
+
+  // Scalar row stepper over rows kbeg + wave, +4, +8, ...: (sequence rb, step rt) of the segT
+  // mapping and the two row pointers.  Inside a sequence a step is two pointer increments; the
+  // pointers are recomputed only when a row crosses into the next sequence.
+  int rk = kbeg + wave, rb = 0, rt = rk;
+  if (segT > 0) { rb = rk / segT; rt = rk - rb * segT; }
+  const long shiftB = g.shift ? 1 : 0;
+  const float *pa, *pb;
+  auto rowptrs = [&]() {
+    const long rowA = segT > 0 ? (long)rb * g.a_seg + rt : (long)rk;
+    const long rowB = (segT > 0 ? (long)rb * g.b_seg + rt : (long)rk) - shiftB;
+    pa = g.A + rowA * g.sak;
+    pb = g.B + rowB * g.sbk;      // with shift at rt == 0 this is never dereferenced
+  };
+  rowptrs();
+  const long stepA = 4 * g.sak, stepB = 4 * g.sbk;
+
+  float4 ra[8];
+  float rbv[8];
+  unsigned okA = 0, okB = 0;        // scalar masks: row e exists for A / B
+  auto fetch = [&](int e) {         // row rk -> slot e, then step to row rk + 4
+    const bool in = rk < kend;
+    const bool inB = in && !(g.shift && rt == 0);
+    ra[e] = gload4((in ? pa : g.A) + a_lane);
+    rbv[e] = gload((inB ? pb : g.B) + b_lane);
+    if (e == 0) { okA = 0; okB = 0; }
+    okA |= in ? (1u << e) : 0u;
+    okB |= inB ? (1u << e) : 0u;
+    rk += 4; rt += 4;
+    if (segT > 0 && rt >= segT) {
+      do { rt -= segT; ++rb; } while (rt >= segT);
+      rowptrs();
+    } else {
+      pa += stepA; pb += stepB;
+    }
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int kr = wave + 4 * e;
+      const bool la = a_in && ((okA >> e) & 1u), lb = b_in && ((okB >> e) & 1u);
+      float4 v;
+      v.x = la ? ra[e].x : 0.0f; v.y = la ? ra[e].y : 0.0f; v.z = la ? ra[e].z : 0.0f; v.w = la ? ra[e].w : 0.0f;
+      *reinterpret_cast<float4*>(As + kr * WLD_A + 4 * lane) = v;
+      Bs[kr * LDS_LD + lane] = lb ? rbv[e] : 0.0f;
+    }
+  };
+
+  f32x16 acc00, acc01, acc10, acc11;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { acc00[i] = 0.0f; acc01[i] = 0.0f; acc10[i] = 0.0f; acc11[i] = 0.0f; }
+  const int aoff = (lane >> 5) * WLD_A + wave * 64 + (lane & 31);
+  const int boff = (lane >> 5) * LDS_LD + (lane & 31);
+
+  if (kbeg < kend) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) fetch(e);
+    store();
+    __syncthreads();
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+      // The wave issues in order, so the next K-block's 8 row fetches (and their scalar
+      // bookkeeping) are spread between the MFMAs instead of running before them with the matrix
+      // pipe idle.  Past the last K-block they read element 0 and are discarded.
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += 2) {
+        if ((kk & 3) == 0) fetch(kk >> 2);
+        const float a0 = As[aoff + kk * WLD_A];
+        const float a1 = As[aoff + 32 + kk * WLD_A];
+        const float b0 = Bs[boff + kk * LDS_LD];
+        const float b1 = Bs[boff + 32 + kk * LDS_LD];
+        acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
+        acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
+        acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
+        acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
+      }
+      __syncthreads();
+      if (k0 + BK < kend) {
+        store();
+        __syncthreads();
+      }
+    }
+  }
+
+  float* C = g.C + (long)bz * g.slab;
+  const int col = n0 + (lane & 31);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = wave * 64 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (row < g.M) {
+      if (col < g.N) C[(long)row * g.ldc + col] = g.alpha * acc00[r];
+      if (col + 32 < g.N) C[(long)row * g.ldc + col + 32] = g.alpha * acc01[r];
+    }
+    if (row + 32 < g.M) {
+      if (col < g.N) C[(long)(row + 32) * g.ldc + col] = g.alpha * acc10[r];
+      if (col + 32 < g.N) C[(long)(row + 32) * g.ldc + col + 32] = g.alpha * acc11[r];
+    }
+  }
+}
+
 // Grouped launch: `table` holds nprob independent problems, all of the TN weight-gradient shape:
 // A = [rows, M] row-major with sam == 1, sak % 4 == 0 and a 16-byte aligned base (loaded with
-// float4 along m), B with arbitrary strides; problem p owns blocks [prefix[p], prefix[p+1]),
-// ordered (z, y, x) with x fastest.  One launch fills the chip with work that would otherwise be
-// a dozen small back-to-back launches.
+// float4 along m), M % 4 == 0 and M <= 256, B with arbitrary strides, no bias / activation /
+// accumulate; problem p owns blocks [prefix[p], prefix[p+1]) of (all M) x 64 output tiles, ordered
+// (z, x) with x fastest.  One launch fills the chip with work that would otherwise be a dozen
+// small back-to-back launches.
 extern "C" __global__ __launch_bounds__(256) void s2g_k_gemm_grouped(const GemmArgs* __restrict__ table,
                                                                      const int* __restrict__ prefix, int nprob) {
-  __shared__ __attribute__((aligned(16))) float As[BK * LDS_LD];
+  __shared__ __attribute__((aligned(16))) float As[BK * WLD_A];
   __shared__ __attribute__((aligned(16))) float Bs[BK * LDS_LD];
-  __shared__ GemmArgs gs;
-  __shared__ int local;
-  if (threadIdx.x == 0) {
-    int p = 0;
-    while (p + 1 < nprob && (int)blockIdx.x >= prefix[p + 1]) ++p;
-    gs = table[p];
-    local = blockIdx.x - prefix[p];
-  }
-  __syncthreads();
-  const int nx = (gs.N + BN - 1) / BN, ny = (gs.M + BM - 1) / BM;
-  const int bx = local % nx, by = (local / nx) % ny, bz = local / (nx * ny);
-  gemm_tile<1, 0>(gs, bx, by, bz, As, Bs);
+  // Workgroups are dealt round-robin to the 8 XCDs (id % 8), each with its own L2.  Remap so that
+  // XCD x works through one contiguous range of logical blocks: the output tiles of one K-slab
+  // (which share that slab's rows of A and B) then run back to back on one L2.
+  const int total = gridDim.x, q = total >> 3, r = total & 7;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  // every thread walks the (uniform) prefix table, so the problem descriptor arrives by scalar
+  // loads and its fields stay in scalar registers
+  int p = 0;
+  while (p + 1 < nprob && lid >= prefix[p + 1]) ++p;
+  const GemmArgs gs = table[p];
+  const int local = lid - prefix[p];
+  const int nx = (gs.N + BN - 1) / BN;
+  const int bx = local % nx, bz = local / nx;
+  wgrad_tile(gs, bx, bz, As, Bs);
 }
 
 // out[perm(r)][c] (+)= scale * sum_z slabs[z][r][c];   perm = internal gate row -> torch row when

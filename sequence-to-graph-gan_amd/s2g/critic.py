@@ -213,9 +213,9 @@ def _wgrad_grouped(eng: "CriticEngine", jobs, cache_key) -> None:
         for (A, K, B, sbk, sbn, segT, a_seg, b_seg, shift) in terms:
             if K <= 0:
                 continue
-            ns = max(1, min(32, (K + 2048) // 4096))
+            ns = max(1, min(128, (K + 512) // 1024))
             kchunk = ((K + ns - 1) // ns + 31) // 32 * 32
-            tiles = ((N + 63) // 64) * ((G4 + 63) // 64)
+            tiles = (N + 63) // 64                               # (all 200 rows) x 64 output tiles
             plan.append((A, K, B, sbk, sbn, segT, a_seg, b_seg, shift, N, ns, kchunk, base_elems + off, slab, blocks))
             sig.append((A, K, B, sbk, sbn, segT, a_seg, b_seg, shift, N))
             blocks += tiles * ns
