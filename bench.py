@@ -100,28 +100,33 @@ def main():
         from s2g.parallel import global_wsum
         pool = [(t, lab, ln, global_wsum(lab_cpu, comm, dev), lab_cpu) for (t, lab, ln, _, lab_cpu) in pool]
 
-    # per-kernel timing of the dominant kernel (forward sweep over 3B sequences): HIP events on the
-    # stream the kernel is launched on, recorded inside the timed region
-    ev = []
+    # per-kernel timing of the five heavy kernels of a critic iteration (the four LSTM sweeps and the
+    # grouped weight-gradient GEMM): HIP events on the stream the kernels are launched on, recorded
+    # inside the timed region
+    ev = {}
     tr.D.timed_events = ev
 
     def one_step(k):
         batches = [pool[(k * N_CRITIC + i) % len(pool)][:4] for i in range(N_CRITIC)]
         tr.full_step(batches)
 
-    for k in range(a.warmup):
-        one_step(k)
-    ev.clear()
-    if comm is not None:
-        comm.barrier()
+    # The step runs on a non-blocking stream of its own: the CU-masked second stream of the critic is a
+    # blocking stream, i.e. it would synchronise implicitly with every launch on the NULL stream.
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(a.steps):
-        one_step(a.warmup + k)
-    if comm is not None:
-        comm.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+        for k in range(a.warmup):
+            one_step(k)
+        ev.clear()
+        if comm is not None:
+            comm.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(a.steps):
+            one_step(a.warmup + k)
+        if comm is not None:
+            comm.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if comm is not None:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -130,15 +135,44 @@ def main():
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
         seqs = N_CRITIC * B_PER_GPU * world * a.steps
-        # dominant kernel: s2g_k_lstm2_fwd on 3B sequences x 512 steps
-        durs = [s.elapsed_time(e) for s, e in ev]
-        kern_ms = sum(durs) / max(len(durs), 1)
-        live = 0
-        for p in pool[:N_CRITIC]:
-            live += int(p[2].sum()) * 2 + B_PER_GPU * GEN_SEQ_LEN      # real + interp lengths, fake Tf
-        live /= N_CRITIC                                                # sequence-steps per launch (average)
-        flops = live * SWEEP_FLOP_PER_STEP
-        achieved = flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
+        # algorithmic FLOP per launch (averaged over the batches of the pool)
+        real = sum(int(p[2].sum()) for p in pool[:N_CRITIC]) / N_CRITIC      # live real steps per batch
+        fake_steps = B_PER_GPU * GEN_SEQ_LEN
+        rows3 = 2 * real + fake_steps                                         # real + interp + fake sequence-steps
+        work = {
+            "s2g_k_lstm2_fwd": rows3 * SWEEP_FLOP_PER_STEP,
+            "s2g_k_lstm2_bwd": rows3 * SWEEP_FLOP_PER_STEP,
+            "s2g_k_lstm2_tangent": real * SWEEP_FLOP_PER_STEP,
+            "s2g_k_lstm2_bwd2": real * SWEEP_FLOP_PER_STEP,
+            # dW_ih0: 4 products of [200 x rows] x [rows x V]; dW_hh0, dW_ih1, dW_hh1: 4 row-blocks x [200 x 50]
+            "s2g_k_gemm_grouped": 2.0 * 200 * (V * (3 * real + fake_steps) + 3 * 50 * (3 * real + fake_steps)),
+        }
+        # "name#phase" entries are the launches of one kernel inside one critic iteration (the grouped
+        # GEMM runs as two launches): their average durations add up to the per-iteration time the
+        # algorithmic work is divided by
+        per_iter, counts, totals, launches = {}, {}, {}, {}
+        for tag, pairs in ev.items():
+            name = tag.split("#")[0]
+            durs = [s.elapsed_time(e) for s, e in pairs]
+            launches[tag] = sum(durs) / max(len(durs), 1)
+            per_iter[name] = per_iter.get(name, 0.0) + sum(durs) / max(len(durs), 1)
+            counts[name] = counts.get(name, 0) + len(durs)
+            totals[name] = totals.get(name, 0.0) + sum(durs)
+        kernels = {}
+        for name, avg in per_iter.items():
+            tf = work[name] / (avg * 1e-3) / 1e12 if avg > 0 else 0.0
+            kernels[name] = {"avg_launch_ms": avg, "launches_timed": counts[name],
+                             "ms_per_step": totals[name] / a.steps, "achieved_tflops": tf,
+                             "frac": tf / FP32_PEAK_TFLOPS}
+        dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+        kern_ms, achieved = kernels[dom]["avg_launch_ms"], kernels[dom]["achieved_tflops"]
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")       # per-launch HBM bytes from rocprofv3 PMC passes
+        if os.path.exists(pmc):
+            with open(pmc) as f:
+                t = json.load(f).get(dom)
+            if t:
+                traffic, traffic_src = t["bytes_per_launch"], t["source"]
         line = {
             "metric": "WGAN-GP train sequences/sec at V=175 L=512", "value": seqs / dt, "unit": "sequences/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
@@ -148,12 +182,16 @@ def main():
                                    f"critic dropout {a.drop_rate}, lengths {a.lengths}",
                        "global_batch": B_PER_GPU * world, "seq_len": L, "parallelism": f"dp{world}"},
             "ms_per_critic_iteration_est": ms_per_step / (N_CRITIC + 0.3),
-            "roofline": {"bound": "mfma", "kernel": "s2g_k_lstm2_fwd (forward sweep, 3B sequences)",
+            "roofline": {"bound": "mfma", "kernel": dom,
                          "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": kern_ms,
-                         "launches_timed": len(durs),
-                         "note": "exact-fp32 recurrence on the VALU, one workgroup per sequence; peak = fp32 "
-                                 "vector/matrix peak; the sweep is dependency-chain bound (512 sequential steps)"},
+                         "frac": achieved / FP32_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "avg_launch_ms": kern_ms, "launches_timed": kernels[dom]["launches_timed"],
+                         "note": "dominant kernel = largest summed time among the five timed kernels; exact-fp32 "
+                                 "arithmetic, peak = fp32 vector = fp32 MFMA peak; the LSTM sweeps are chains of 512 "
+                                 "dependent steps (one workgroup per sequence) and are bounded by per-step latency, "
+                                 "not by the FLOP or HBM roof"},
+            "kernels": kernels, "launch_avg_ms": launches,
+            "second_stream": ("cu-masked, 3/4 of the CUs" if tr.D._side else None),
         }
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()

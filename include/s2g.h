@@ -157,6 +157,14 @@ int s2g_bn_bwd_apply(const float* dyh, const float* xhat, const float* sums, flo
 int s2g_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
              int step, float gscale, void* stream);
 
+/* ---- streams.  No counterpart in the reference (its step is one serial autograd graph,
+ * wgan_gp.py:297-317): the second-order sweeps of the penalty run one workgroup per sequence and
+ * occupy B of the 256 CUs, so the host runs the work that does not depend on them on a second HIP
+ * stream confined to the other CUs.  mask: bit i of word i/32 enables CU i for kernels launched on
+ * the stream (hipExtStreamCreateWithCUMask). */
+int s2g_stream_create_cu_mask(const unsigned* mask, int nwords, void** stream_out);
+int s2g_stream_destroy(void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -274,12 +274,25 @@ extern "C" __global__ void s2g_k_head_bwd_w(const float* __restrict__ dout, cons
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= J * S2G_H) return;
   int j = i / S2G_H, k = i % S2G_H;
-  float s = 0.0f, sb = 0.0f;
-  for (int n = 0; n < N; ++n) {
-    float d = dout[n * J + j];
-    s = fmaf(d, hT[(long)n * S2G_H + k], s);
-    sb += d;
+  // four independent partial sums: the loads of a group are in flight together instead of one
+  // memory round trip per sample
+  float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f, q0 = 0.0f, q1 = 0.0f, q2 = 0.0f, q3 = 0.0f;
+  int n = 0;
+  for (; n + 4 <= N; n += 4) {
+    const float d0 = dout[n * J + j], d1 = dout[(n + 1) * J + j], d2 = dout[(n + 2) * J + j],
+                d3 = dout[(n + 3) * J + j];
+    p0 = fmaf(d0, hT[(long)n * S2G_H + k], p0);
+    p1 = fmaf(d1, hT[(long)(n + 1) * S2G_H + k], p1);
+    p2 = fmaf(d2, hT[(long)(n + 2) * S2G_H + k], p2);
+    p3 = fmaf(d3, hT[(long)(n + 3) * S2G_H + k], p3);
+    q0 += d0; q1 += d1; q2 += d2; q3 += d3;
   }
+  for (; n < N; ++n) {
+    const float d = dout[n * J + j];
+    p0 = fmaf(d, hT[(long)n * S2G_H + k], p0);
+    q0 += d;
+  }
+  const float s = (p0 + p1) + (p2 + p3), sb = (q0 + q1) + (q2 + q3);
   dW[i] = accumulate ? dW[i] + s : s;
   if (k == 0) db[j] = accumulate ? db[j] + sb : sb;
 }

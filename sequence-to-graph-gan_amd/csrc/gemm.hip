@@ -213,12 +213,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
     __syncthreads();
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
       const bool more = (k0 + BK) < kend;
-      if (more) {
-        la.load(g.A, g.sam, g.sak, g.a_seg, g.segT, false, m0, g.M, k0 + BK, kend);
-        lb.load(g.B, g.sbn, g.sbk, g.b_seg, g.segT, g.shift != 0, n0, g.N, k0 + BK, kend);
-      }
+      // the wave issues in order: the next K-block's loads (and their address arithmetic) go between
+      // the MFMAs, not in front of them with the matrix pipe idle
 #pragma unroll
       for (int kk = 0; kk < BK; kk += 2) {
+        if (kk == 2 && more) la.load(g.A, g.sam, g.sak, g.a_seg, g.segT, false, m0, g.M, k0 + BK, kend);
+        if (kk == 10 && more) lb.load(g.B, g.sbn, g.sbk, g.b_seg, g.segT, g.shift != 0, n0, g.N, k0 + BK, kend);
         float a = As[aoff + kk * LDS_LD];
         float b = Bs[boff + kk * LDS_LD];
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
@@ -407,21 +407,31 @@ extern "C" __global__ __launch_bounds__(256) void s2g_k_gemm_grouped(const GemmA
 }
 
 // out[perm(r)][c] (+)= scale * sum_z slabs[z][r][c];   perm = internal gate row -> torch row when
-// permute_rows, identity otherwise.  One thread per output element.
-extern "C" __global__ void s2g_k_reduce_slabs(const float* __restrict__ slabs, long slab, int nslab,
-                                              int rows, int cols, float* __restrict__ out,
-                                              int permute_rows, int accumulate, float scale) {
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long)rows * cols) return;
-  int r = (int)(i / cols), c = (int)(i % cols);
+// permute_rows, identity otherwise.  A block of 4 waves owns 64 consecutive output elements; wave w
+// sums slabs w, w+4, w+8, ... (four loads in flight per thread), the partial sums meet in LDS.  The
+// summation order is fixed by (nslab), so results are reproducible run to run.
+extern "C" __global__ __launch_bounds__(256) void s2g_k_reduce_slabs(const float* __restrict__ slabs, long slab,
+                                                                     int nslab, int rows, int cols,
+                                                                     float* __restrict__ out, int permute_rows,
+                                                                     int accumulate, float scale) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + lane;
+  const bool ok = i < (long)rows * cols;
   float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-  int z = 0;
-  for (; z + 4 <= nslab; z += 4) {
-    s0 += slabs[(long)z * slab + i]; s1 += slabs[(long)(z + 1) * slab + i];
-    s2 += slabs[(long)(z + 2) * slab + i]; s3 += slabs[(long)(z + 3) * slab + i];
+  if (ok) {
+    int z = w;
+    for (; z + 12 < nslab; z += 16) {
+      s0 += slabs[(long)z * slab + i]; s1 += slabs[(long)(z + 4) * slab + i];
+      s2 += slabs[(long)(z + 8) * slab + i]; s3 += slabs[(long)(z + 12) * slab + i];
+    }
+    for (; z < nslab; z += 4) s0 += slabs[(long)z * slab + i];
   }
-  for (; z < nslab; ++z) s0 += slabs[(long)z * slab + i];
-  float s = (s0 + s1) + (s2 + s3);
+  red[w][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (w != 0 || !ok) return;
+  float s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  const int r = (int)(i / cols), c = (int)(i % cols);
   int ro = permute_rows ? pt_row(r) : r;
   long o = (long)ro * cols + c;
   s *= scale;

@@ -57,7 +57,7 @@ int s2g_reduce_slabs(const float* slabs, long slab, int nslab, int rows, int col
                      int accumulate, float scale, void* stream) {
   if (!slabs || !out || nslab <= 0 || rows <= 0 || cols <= 0) return -1;
   if (permute_rows && rows != S2G_G) return -1;
-  hipLaunchKernelGGL(s2g_k_reduce_slabs, dim3(cdiv((long)rows * cols, 256)), dim3(256), 0, ST(stream), slabs,
+  hipLaunchKernelGGL(s2g_k_reduce_slabs, dim3(cdiv((long)rows * cols, 64)), dim3(256), 0, ST(stream), slabs,
                      slab, nslab, rows, cols, out, permute_rows, accumulate, scale);
   return LAUNCH_OK();
 }
@@ -257,6 +257,24 @@ int s2g_adam(float* p, const float* g, float* m, float* v, long n, float lr, flo
   hipLaunchKernelGGL(s2g_k_adam, dim3(blocks), dim3(256), 0, ST(stream), p, g, m, v, n, b1, b2, eps, step_size,
                      inv_sqrt_bc2, gscale);
   return LAUNCH_OK();
+}
+
+int s2g_stream_create_cu_mask(const unsigned* mask, int nwords, void** stream_out) {
+  if (!mask || nwords <= 0 || !stream_out) return -1;
+  hipStream_t s = nullptr;
+  const hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)nwords, mask);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();      // the runtime refuses some mask shapes; do not leave the error for the next launch check
+    return -(int)e - 1000;
+  }
+  *stream_out = (void*)s;
+  return 0;
+}
+
+int s2g_stream_destroy(void* stream) {
+  if (!stream) return -1;
+  S2G_CHECK(hipStreamDestroy((hipStream_t)stream));
+  return 0;
 }
 
 }  // extern "C"

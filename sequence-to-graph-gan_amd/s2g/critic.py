@@ -58,8 +58,11 @@ class CriticEngine:
         self.b0 = torch.empty(G4, device=device)
         self.b1 = torch.empty(G4, device=device)
         self.scratch = ops.Scratch(device)
-        self.timed_events = None      # list -> (start, end) HIP event pairs around the 3B-sequence forward sweep
+        self.timed_events = None      # dict kernel name -> [(start, end) HIP event pairs] (benchmark hook)
         self._gemm_tables = {}        # cached device-side problem tables of the grouped weight-gradient GEMM
+        self._wgrad_slabs = None      # split-K slabs of the weight-gradient products
+        self.overlap = True           # run the work that does not depend on sweeps C/D beside them (critic_iteration)
+        self._side = None             # (stream, fork event, join event, scratch) of that second stream
         self._ws_key = None
         self.ws: Dict[str, torch.Tensor] = {}
 
@@ -125,18 +128,53 @@ class CriticEngine:
         rows = x.numel() // self.V
         ops.gemm_raw(ptr(x), self.V, 1, ptr(self.WT0), G4, 1, ptr(out), G4, rows, G4, self.V)
 
-    def sweep_fwd(self, ws, desc_ptr, nseq, max_len, tokens, P, mask, timed: bool = False) -> None:
+    def side(self):
+        """The second HIP stream of critic_iteration, confined to 3/4 of the CUs: sweeps C and D run
+        one workgroup per sequence of the interp third (B workgroups, each filling a CU's register
+        file) and find the reserved quarter of the chip free, while the weight-gradient products that
+        only need sweep B fill the rest.  The mask enables the first 3/4 of the CU bits; the driver
+        deals mask bits round-robin to the 8 XCDs, so every XCD keeps a quarter of its CUs free.
+        Returns None (no overlap, one stream) where the runtime refuses the mask: an unmasked second
+        stream would let the GEMM occupy every CU and starve the sweeps' workgroups."""
+        if self._side is None:
+            import ctypes
+            n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count
+            words = (n_cu + 31) // 32
+            mask = (ctypes.c_uint32 * words)()
+            for i in range(n_cu * 3 // 4):
+                mask[i // 32] |= 1 << (i % 32)
+            handle = ctypes.c_void_p()
+            try:
+                call("s2g_stream_create_cu_mask", mask, words, ctypes.byref(handle))
+            except S2GError:
+                self._side = False
+                return None
+            stream = torch.cuda.ExternalStream(handle.value, device=self.device)
+            # The masked stream is a blocking stream (the call takes no flags): it synchronises
+            # implicitly with the NULL stream, torch's default.  The sweeps it must run beside are
+            # therefore put on a third, non-blocking stream for the duration of the overlap.
+            ev = [torch.cuda.Event() for _ in range(4)]      # fork, after sweep C, join (stream2), join (stream_c)
+            self._side = (stream, torch.cuda.Stream(device=self.device), *ev, ops.Scratch(self.device))
+        return self._side or None
+
+    def timed(self, name: str, fn) -> None:
+        """Runs fn(); when the benchmark hook is set, brackets it with HIP events on the current stream
+        (the one every libs2g launch of this engine goes to)."""
+        te = self.timed_events
+        if te is None:
+            fn()
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        te.setdefault(name, []).append((e0, e1))
+
+    def sweep_fwd(self, ws, desc_ptr, nseq, max_len, tokens, P, mask) -> None:
         whh0, wih1, whh1 = self._w()
-        te = self.timed_events if timed else None
-        if te is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
         call("s2g_lstm2_fwd", desc_ptr, nseq, max_len, ptr(tokens), ptr(self.WT0), ptr(P), ptr(mask), ptr(self.b0),
              ptr(self.b1), whh0, wih1, whh1, ptr(ws["gates0"]), ptr(ws["cell0"]), ptr(ws["gates1"]),
              ptr(ws["cell1"]), ptr(ws["hT"]), stream_ptr())
-        if te is not None:
-            e1.record()
-            te.append((e0, e1))
 
     def head_fwd(self, ws, nseq) -> None:
         p = self.params.views
@@ -195,56 +233,91 @@ def _wgrad(eng: "CriticEngine", out: torch.Tensor, N: int, terms) -> None:
     _wgrad_grouped(eng, [(out, N, terms)], "single")
 
 
-def _wgrad_grouped(eng: "CriticEngine", jobs, cache_key) -> None:
-    """jobs: list of (out tensor [200,N] torch layout, N, terms).  Every product of every job runs
-    in ONE grouped GEMM launch (split-K slabs), then one reduce per job.  The device-side problem
-    table is cached per `cache_key` and rebuilt only when a pointer or size changes."""
-    import ctypes
+def _wgrad_build(eng: "CriticEngine", jobs, cache_key):
+    """jobs: list of (out tensor [200,N] torch layout, N, terms); a term is
+    (A_ptr, K, B_ptr, sbk, sbn, segT, a_seg, b_seg, shift[, phase]).  All products of one phase run
+    in ONE grouped GEMM launch; every product owns its split-K slabs, one reduce per job sums the
+    slabs of all phases.  Returns (tables {phase: (table, prefix, nprob, nblocks)}, job_slabs,
+    slabs); the device-side tables are cached per `cache_key` and rebuilt only when a pointer or
+    size changes."""
     from .lib import S2GGemm
-    plan, sig = [], []
-    total_slabs, blocks = 0, 0
-    job_slabs = []
+    # K-chunk per phase: 1024 rows unless that leaves the launch with fewer than ~3 blocks per CU
+    # (the kernel hides its loads behind the MFMAs of the other blocks on the CU)
+    chunk = {}
+    for _, N, terms in jobs:
+        for term in terms:
+            ph = term[9] if len(term) > 9 else 0
+            chunk.setdefault(ph, []).append(((N + 63) // 64, term[1]))
+    for ph, lst in chunk.items():
+        c = 1024
+        while c > 256 and sum(t * ((K + c - 1) // c) for t, K in lst if K > 0) < 700:
+            c //= 2
+        chunk[ph] = c
+    plan, sig, job_slabs = [], [], []
+    base = 0
     for out, N, terms in jobs:
         slab = G4 * N
-        first = total_slabs
-        base_elems = sum(js[1] * js[2] for js in job_slabs)
-        off = 0
         nsl = 0
-        for (A, K, B, sbk, sbn, segT, a_seg, b_seg, shift) in terms:
+        for term in terms:
+            A, K, B, sbk, sbn, segT, a_seg, b_seg, shift = term[:9]
+            phase = term[9] if len(term) > 9 else 0
             if K <= 0:
                 continue
-            ns = max(1, min(128, (K + 512) // 1024))
+            c = chunk[phase]
+            ns = max(1, min(256, (K + c // 2) // c))
             kchunk = ((K + ns - 1) // ns + 31) // 32 * 32
             tiles = (N + 63) // 64                               # (all 200 rows) x 64 output tiles
-            plan.append((A, K, B, sbk, sbn, segT, a_seg, b_seg, shift, N, ns, kchunk, base_elems + off, slab, blocks))
-            sig.append((A, K, B, sbk, sbn, segT, a_seg, b_seg, shift, N))
-            blocks += tiles * ns
-            off += ns * slab
+            plan.append((phase, A, K, B, sbk, sbn, segT, a_seg, b_seg, shift, N, kchunk, base + nsl * slab, slab,
+                         tiles * ns))
+            sig.append((phase, A, K, B, sbk, sbn, segT, a_seg, b_seg, shift, N))
             nsl += ns
-        job_slabs.append((out, nsl, slab, base_elems))
-        total_slabs += nsl
-    need = sum(js[1] * js[2] for js in job_slabs)
-    slabs = eng.scratch.get(need)
+        job_slabs.append((out, nsl, slab, base))
+        base += nsl * slab
+    if eng._wgrad_slabs is None or eng._wgrad_slabs.numel() < base:
+        eng._wgrad_slabs = torch.empty(max(base, 1), dtype=torch.float32, device=eng.device)
+    slabs = eng._wgrad_slabs
     sig = (tuple(sig), slabs.data_ptr())
     cache = eng._gemm_tables.get(cache_key)
     if cache is None or cache[0] != sig:
-        arr = (S2GGemm * len(plan))()
-        prefix = []
-        for i, (A, K, B, sbk, sbn, segT, a_seg, b_seg, shift, N, ns, kchunk, soff, slab, b0) in enumerate(plan):
-            arr[i] = S2GGemm(A, 1, G4, B, sbk, sbn, ptr(slabs, soff), N, slab, None, G4, N, K, kchunk, segT, a_seg,
-                             b_seg, int(shift), 0, 0, 1.0)
-            prefix.append(b0)
-        prefix.append(blocks)
-        raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(eng.device)
-        pre = torch.tensor(prefix, dtype=torch.int32, device=eng.device)
-        cache = (sig, raw, pre, len(plan), blocks)
+        tables = {}
+        for ph in sorted({e[0] for e in plan}):
+            sel = [e for e in plan if e[0] == ph]
+            arr = (S2GGemm * len(sel))()
+            prefix, blocks = [], 0
+            for i, (_, A, K, B, sbk, sbn, segT, a_seg, b_seg, shift, N, kchunk, soff, slab, nblk) in enumerate(sel):
+                arr[i] = S2GGemm(A, 1, G4, B, sbk, sbn, ptr(slabs, soff), N, slab, None, G4, N, K, kchunk, segT,
+                                 a_seg, b_seg, int(shift), 0, 0, 1.0)
+                prefix.append(blocks)
+                blocks += nblk
+            prefix.append(blocks)
+            raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(eng.device)
+            pre = torch.tensor(prefix, dtype=torch.int32, device=eng.device)
+            tables[ph] = (raw, pre, len(sel), blocks)
+        cache = (sig, tables)
         eng._gemm_tables[cache_key] = cache
-    _, raw, pre, nprob, nblocks = cache
-    call("s2g_gemm_grouped", ptr(raw), ptr(pre), nprob, nblocks, stream_ptr())
+    return cache[1], job_slabs, slabs
+
+
+def _wgrad_launch(eng: "CriticEngine", built, phase: int) -> None:
+    t = built[0].get(phase)
+    if t is not None:
+        raw, pre, nprob, nblocks = t
+        eng.timed(f"s2g_k_gemm_grouped#{phase}",
+                  lambda: call("s2g_gemm_grouped", ptr(raw), ptr(pre), nprob, nblocks, stream_ptr()))
+
+
+def _wgrad_reduce(eng: "CriticEngine", built) -> None:
+    _, job_slabs, slabs = built
     for out, nsl, slab, base in job_slabs:
         if nsl:
-            N = slab // G4
-            call("s2g_reduce_slabs", ptr(slabs, base), slab, nsl, G4, N, ptr(out), 1, 0, 1.0, stream_ptr())
+            call("s2g_reduce_slabs", ptr(slabs, base), slab, nsl, G4, slab // G4, ptr(out), 1, 0, 1.0, stream_ptr())
+
+
+def _wgrad_grouped(eng: "CriticEngine", jobs, cache_key) -> None:
+    built = _wgrad_build(eng, jobs, cache_key)
+    for ph in sorted(built[0]):
+        _wgrad_launch(eng, built, ph)
+    _wgrad_reduce(eng, built)
 
 
 def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Tensor, labels: torch.Tensor,
@@ -282,7 +355,7 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         ws["xhat"] = torch.empty(B * T, V, device=eng.device)
     # sweep A on 3B sequences
     eng.project(fake, ws["Pf"])
-    eng.sweep_fwd(ws, dptr, 3 * B, Tw, tokens, ws["Pf"], mask, timed=True)
+    eng.timed("s2g_k_lstm2_fwd", lambda: eng.sweep_fwd(ws, dptr, 3 * B, Tw, tokens, ws["Pf"], mask))
     eng.head_fwd(ws, 3 * B)
     inv_n = 1.0 / float(n_global)
     call("s2g_critic_loss", ptr(ws["out"]), ptr(labels), B, inv_n, inv_wsum, class_w[0], class_w[1],
@@ -290,47 +363,82 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
     call("s2g_head_bwd_dh", ptr(ws["dout"]), ptr(p["fc.weight"]), ptr(ws["dhT"]), 3 * B, 3, st)
     call("s2g_head_bwd_w", ptr(ws["dout"]), ptr(ws["hT"]), ptr(g["fc.weight"]), ptr(g["fc.bias"]), 2 * B, 3, 0, st)
     # sweep B on 3B sequences (the interp third with d(out) = e0 and stored adjoints)
-    eng.sweep_bwd(ws, dptr, 3 * B, Tw, mask, adj_seq0=2 * B)
+    eng.timed("s2g_k_lstm2_bwd", lambda: eng.sweep_bwd(ws, dptr, 3 * B, Tw, mask, adj_seq0=2 * B))
     # input gradient of the interp third, its norm, the penalty and the direction v (in place)
     r_int = 2 * B * Tw
     ops.gemm_raw(ptr(ws["delta0"], r_int * G4), G4, 1, ptr(eng.W0p), V, 1, ptr(ws["G"]), V, B * Tw, V, G4)
     call("s2g_gp_norm_penalty", ptr(ws["G"]), B, Tw * V, float(lambda_gp), float(n_global), ptr(ws["pen"]),
          ptr(ws["norms"]), 1, st)
-    eng.project(ws["G"], ws["Pv"])
-    # sweeps C and D on the interp third (group-relative descriptors = 4th block of desc)
-    drel = ptr(desc, 3 * B * 8)
-    mrel = ptr(mask, r_int * MASKW) if mask is not None else None
-    eng.sweep_tangent(ws, drel, B, mrel, r_int)
-    eng.sweep_bwd2(ws, drel, B, Tw, mrel, r_int)
-    # operands of the weight-gradient products
-    call("s2g_one_hot", ptr(tokens), ptr(lengths), T, ptr(ws["xreal"]), B * T, V, st)
-    call("s2g_gp_interp", ptr(tokens), ptr(lengths), ptr(fake), ptr(alpha), B, T, Tf, V, ptr(ws["xhat"]), st)
     d0, d1, c0, c1 = ws["delta0"], ws["delta1"], ws["cell0"], ws["cell1"]
     a0, a1, cd0, cd1 = ws["abar0"], ws["abar1"], ws["celld0"], ws["celld1"]
     oi = r_int * G4
     n12, n3 = 2 * B * Tw, B * Tw
+    # weight-gradient products; the last field is the phase = the last sweep the product needs:
+    # 0 = A/B, 1 = C (tangent states), 2 = D (adjoints abar)
     jobs = [(g["lstm.weight_ih_l0"], V, [
-        (ptr(d0), B * T, ptr(ws["xreal"]), V, 1, T, Tw, T, False),
-        (ptr(d0, B * Tw * G4), B * Tf, ptr(fake), V, 1, Tf, Tw, Tf, False),
-        (ptr(a0), B * T, ptr(ws["xhat"]), V, 1, T, Tw, T, False),
-        (ptr(d0, oi), n3, ptr(ws["G"]), V, 1, 0, 0, 0, False)]),
+        (ptr(d0), B * T, ptr(ws["xreal"]), V, 1, T, Tw, T, False, 0),
+        (ptr(d0, B * Tw * G4), B * Tf, ptr(fake), V, 1, Tf, Tw, Tf, False, 0),
+        (ptr(d0, oi), n3, ptr(ws["G"]), V, 1, 0, 0, 0, False, 0),
+        (ptr(a0), B * T, ptr(ws["xhat"]), V, 1, T, Tw, T, False, 2)]),
             (g["lstm.weight_hh_l0"], H, [
-        (ptr(d0), n12, ptr(c0, 2), G4, 4, Tw, Tw, Tw, True),
-        (ptr(a0), n3, ptr(c0, oi + 2), G4, 4, Tw, Tw, Tw, True),
-        (ptr(d0, oi), n3, ptr(cd0, 1), G4, 4, Tw, Tw, Tw, True)]),
+        (ptr(d0), n12, ptr(c0, 2), G4, 4, Tw, Tw, Tw, True, 0),
+        (ptr(a0), n3, ptr(c0, oi + 2), G4, 4, Tw, Tw, Tw, True, 2),
+        (ptr(d0, oi), n3, ptr(cd0, 1), G4, 4, Tw, Tw, Tw, True, 1)]),
             (g["lstm.weight_ih_l1"], H, [
-        (ptr(d1), n12, ptr(c0, 3), G4, 4, 0, 0, 0, False),
-        (ptr(a1), n3, ptr(c0, oi + 3), G4, 4, 0, 0, 0, False),
-        (ptr(d1, oi), n3, ptr(cd0, 2), G4, 4, 0, 0, 0, False)]),
+        (ptr(d1), n12, ptr(c0, 3), G4, 4, 0, 0, 0, False, 0),
+        (ptr(a1), n3, ptr(c0, oi + 3), G4, 4, 0, 0, 0, False, 2),
+        (ptr(d1, oi), n3, ptr(cd0, 2), G4, 4, 0, 0, 0, False, 1)]),
             (g["lstm.weight_hh_l1"], H, [
-        (ptr(d1), n12, ptr(c1, 2), G4, 4, Tw, Tw, Tw, True),
-        (ptr(a1), n3, ptr(c1, oi + 2), G4, 4, Tw, Tw, Tw, True),
-        (ptr(d1, oi), n3, ptr(cd1, 1), G4, 4, Tw, Tw, Tw, True)])]
-    _wgrad_grouped(eng, jobs, ("critic", B, T, Tf))
+        (ptr(d1), n12, ptr(c1, 2), G4, 4, Tw, Tw, Tw, True, 0),
+        (ptr(a1), n3, ptr(c1, oi + 2), G4, 4, Tw, Tw, Tw, True, 2),
+        (ptr(d1, oi), n3, ptr(cd1, 1), G4, 4, Tw, Tw, Tw, True, 1)])]
+    built = _wgrad_build(eng, jobs, ("critic", B, T, Tf))
+
+    def first_order(sc):
+        """Everything that needs sweeps A and B only: operands of the products, their phase-0 part, the
+        first-order bias gradients."""
+        s_ = stream_ptr()
+        call("s2g_one_hot", ptr(tokens), ptr(lengths), T, ptr(ws["xreal"]), B * T, V, s_)
+        call("s2g_gp_interp", ptr(tokens), ptr(lengths), ptr(fake), ptr(alpha), B, T, Tf, V, ptr(ws["xhat"]), s_)
+        _wgrad_launch(eng, built, 0)
+        ops.colsum(d0, n12, G4, G4, g["lstm.bias_ih_l0"], sc, permute_rows=True)
+        ops.colsum(d1, n12, G4, G4, g["lstm.bias_ih_l1"], sc, permute_rows=True)
+
+    drel = ptr(desc, 3 * B * 8)          # group-relative descriptors of the interp third = 4th block of desc
+    mrel = ptr(mask, r_int * MASKW) if mask is not None else None
+
     sc = eng.scratch
-    ops.colsum(d0, n12, G4, G4, g["lstm.bias_ih_l0"], sc, permute_rows=True)
+    side = eng.side() if eng.overlap else None
+    if side is not None:
+        # stream_c: project, sweep C, sweep D (B workgroups on the reserved quarter of the CUs)
+        # stream2 : products of phase 0 beside sweep C, products of phase 1 beside sweep D
+        stream2, stream_c, fork, after_c, join, join_c, sc2 = side
+        fork.record()
+        with torch.cuda.stream(stream_c):
+            stream_c.wait_event(fork)
+            eng.project(ws["G"], ws["Pv"])
+            eng.timed("s2g_k_lstm2_tangent", lambda: eng.sweep_tangent(ws, drel, B, mrel, r_int))
+            after_c.record()
+            eng.timed("s2g_k_lstm2_bwd2", lambda: eng.sweep_bwd2(ws, drel, B, Tw, mrel, r_int))
+            join_c.record()
+        with torch.cuda.stream(stream2):
+            stream2.wait_event(fork)
+            first_order(sc2)
+            stream2.wait_event(after_c)
+            _wgrad_launch(eng, built, 1)
+            join.record()
+        cur = torch.cuda.current_stream()
+        cur.wait_event(join_c)
+        cur.wait_event(join)
+    else:
+        eng.project(ws["G"], ws["Pv"])
+        eng.timed("s2g_k_lstm2_tangent", lambda: eng.sweep_tangent(ws, drel, B, mrel, r_int))
+        eng.timed("s2g_k_lstm2_bwd2", lambda: eng.sweep_bwd2(ws, drel, B, Tw, mrel, r_int))
+        first_order(sc)
+        _wgrad_launch(eng, built, 1)
+    _wgrad_launch(eng, built, 2)
+    _wgrad_reduce(eng, built)
     ops.colsum(a0, n3, G4, G4, g["lstm.bias_ih_l0"], sc, permute_rows=True, accumulate=True)
-    ops.colsum(d1, n12, G4, G4, g["lstm.bias_ih_l1"], sc, permute_rows=True)
     ops.colsum(a1, n3, G4, G4, g["lstm.bias_ih_l1"], sc, permute_rows=True, accumulate=True)
     g["lstm.bias_hh_l0"].copy_(g["lstm.bias_ih_l0"])
     g["lstm.bias_hh_l1"].copy_(g["lstm.bias_ih_l1"])

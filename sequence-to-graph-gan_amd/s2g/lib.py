@@ -62,6 +62,8 @@ SIGNATURES = {
     "s2g_bn_lrelu_bwd_stats": [P, P, P, P, I, I, P],
     "s2g_bn_bwd_apply": [P, P, P, F, P, P, P, I, I, P],
     "s2g_adam": [P, P, P, P, L, F, F, F, F, I, F, P],
+    "s2g_stream_create_cu_mask": [P, I, P],
+    "s2g_stream_destroy": [P],
 }
 
 

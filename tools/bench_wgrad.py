@@ -67,6 +67,15 @@ def main():
         return e0.elapsed_time(e1) / reps * 1e3
 
     print(f"W_ih0 only (N=175): {timeit(jobs[:1], 'b0'):.1f} us;  three N=50 jobs: {timeit(jobs[1:], 'b1'):.1f} us")
+    if "--side" in sys.argv:       # the same launch on the CU-masked second stream (3/4 of the CUs)
+        side = eng.side()
+        if side is None:
+            print("CU-masked stream refused by the runtime")
+        else:
+            torch.cuda.synchronize()
+            with torch.cuda.stream(side[0]):
+                print(f"all jobs on the masked stream: {timeit(jobs, 'bench'):.1f} us")
+            torch.cuda.synchronize()
     us = timeit(jobs, "bench")
     flops = 2.0 * G4 * (4 * V * n3 + 3 * H * (n12 + 2 * n3))
     print(f"wgrad grouped + reduces: {us:.1f} us  ({flops / us * 1e-6:.1f} TFLOP/s algorithmic)")

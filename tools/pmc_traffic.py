@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Turns two rocprofv3 PMC passes over bench.py (one with --pmc FETCH_SIZE, one with --pmc WRITE_SIZE,
+each with --kernel-trace --output-format csv) into profiles/pmc_traffic.json: HBM bytes per launch of
+every libs2g kernel.
+
+    python tools/pmc_traffic.py <fetch_dir> <write_dir> <tag>
+
+FETCH_SIZE / WRITE_SIZE are reported in KiB.  On gfx950 FETCH_SIZE counts 64 B per 128-B read request,
+i.e. half the bytes of coalesced wide reads, so it is doubled; WRITE_SIZE is taken as is.  Check of the
+doubling on this code's own access pattern: s2g_k_lstm2_bwd2 reads 4 x 800 + 400 B per (row, layer) over
+2 x 32768 rows = 236 MB by construction, and 2 x FETCH_SIZE = 238 MB."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def per_kernel(d, counter):
+    f = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))[0]
+    tot, cnt = collections.defaultdict(float), collections.Counter()
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()
+        tot[k] += float(r["Counter_Value"])
+        cnt[k] += 1
+    return {k: tot[k] / cnt[k] for k in tot}
+
+
+def main():
+    fetch_dir, write_dir, tag = sys.argv[1:4]
+    fe, wr = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
+    out = {}
+    for k in sorted(set(fe) | set(wr)):
+        if not k.startswith("s2g_k_"):
+            continue
+        rd, w = 2.0 * fe.get(k, 0.0) * 1024.0, wr.get(k, 0.0) * 1024.0
+        out[k] = {"bytes_per_launch": rd + w, "read_bytes": rd, "write_bytes": w,
+                  "source": f"profiles/{tag}_pmc_fetch.csv + profiles/{tag}_pmc_write.csv (rocprofv3 --pmc FETCH_SIZE / "
+                            "WRITE_SIZE, separate passes; FETCH_SIZE doubled per the gfx950 correction), mean over launches"}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "profiles", "pmc_traffic.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    for k, v in out.items():
+        print(f"{k:36s} {v['bytes_per_launch'] / 1e6:10.1f} MB/launch (read {v['read_bytes'] / 1e6:.1f}, write {v['write_bytes'] / 1e6:.1f})")
+
+
+if __name__ == "__main__":
+    main()
