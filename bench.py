@@ -123,6 +123,7 @@ def main():
         t0 = time.perf_counter()
         for k in range(a.steps):
             one_step(a.warmup + k)
+        t_host = time.perf_counter() - t0          # host time to enqueue the steps (launch-bound if close to dt)
         if comm is not None:
             comm.barrier()
         torch.cuda.synchronize()
@@ -182,6 +183,7 @@ def main():
                                    f"critic dropout {a.drop_rate}, lengths {a.lengths}",
                        "global_batch": B_PER_GPU * world, "seq_len": L, "parallelism": f"dp{world}"},
             "ms_per_critic_iteration_est": ms_per_step / (N_CRITIC + 0.3),
+            "host_enqueue_ms_per_step": t_host / a.steps * 1e3,
             "roofline": {"bound": "mfma", "kernel": dom,
                          "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,

@@ -150,6 +150,14 @@ class CriticEngine:
                 self._side = False
                 return None
             stream = torch.cuda.ExternalStream(handle.value, device=self.device)
+            import atexit
+
+            def close(h=handle.value, dev=self.device):
+                # destroy the stream while the HIP runtime is still up (leaving it to process teardown
+                # crashes in a runtime finalizer)
+                torch.cuda.synchronize(dev)
+                call("s2g_stream_destroy", h)
+            atexit.register(close)
             # The masked stream is a blocking stream (the call takes no flags): it synchronises
             # implicitly with the NULL stream, torch's default.  The sweeps it must run beside are
             # therefore put on a third, non-blocking stream for the duration of the overlap.
@@ -322,9 +330,13 @@ def _wgrad_grouped(eng: "CriticEngine", jobs, cache_key) -> None:
 
 def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Tensor, labels: torch.Tensor,
                      fake: torch.Tensor, alpha: torch.Tensor, lambda_gp: float, n_global: int, inv_wsum: float,
-                     mask: Optional[torch.Tensor] = None, class_w=(1.0, 2.0)):
+                     mask: Optional[torch.Tensor] = None, class_w=(1.0, 2.0), prefetch=None):
     """One critic loss + gradient evaluation (wgan_gp.py:297-317) on the batch
     [real B | fake B | interp B], all three passes sharing each of the four sweeps.
+
+    prefetch: optional callable launched on the second stream after this iteration's own work there
+    (the trainer generates the next iteration's fake batch in it); it is NOT waited for here, the
+    caller synchronises with whatever it enqueued.
 
     tokens int32 [B,T] (zero padded), lengths int32 [B], labels int64 [B], fake fp32 [B,Tf,V],
     alpha fp32 [B] (the draw of wgan_gp.py:228), mask fp32 [3*B*Tw, 52] or None.
@@ -392,7 +404,7 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         (ptr(d1), n12, ptr(c1, 2), G4, 4, Tw, Tw, Tw, True, 0),
         (ptr(a1), n3, ptr(c1, oi + 2), G4, 4, Tw, Tw, Tw, True, 2),
         (ptr(d1, oi), n3, ptr(cd1, 1), G4, 4, Tw, Tw, Tw, True, 1)])]
-    built = _wgrad_build(eng, jobs, ("critic", B, T, Tf))
+    built = _wgrad_build(eng, jobs, ("critic", B, T, Tf, fake.data_ptr()))
 
     def first_order(sc):
         """Everything that needs sweeps A and B only: operands of the products, their phase-0 part, the
@@ -427,6 +439,8 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
             stream2.wait_event(after_c)
             _wgrad_launch(eng, built, 1)
             join.record()
+            if prefetch is not None:
+                prefetch()          # not part of the join: it may run on beside this iteration's tail
         cur = torch.cuda.current_stream()
         cur.wait_event(join_c)
         cur.wait_event(join)
@@ -436,6 +450,8 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         eng.timed("s2g_k_lstm2_bwd2", lambda: eng.sweep_bwd2(ws, drel, B, Tw, mrel, r_int))
         first_order(sc)
         _wgrad_launch(eng, built, 1)
+        if prefetch is not None:
+            prefetch()
     _wgrad_launch(eng, built, 2)
     _wgrad_reduce(eng, built)
     ops.colsum(a0, n3, G4, G4, g["lstm.bias_ih_l0"], sc, permute_rows=True, accumulate=True)

@@ -53,7 +53,10 @@ class WGANGPTrainer:
         self.mG, self.vG = self.mG_named.flat, self.vG_named.flat
         self.tD = 0
         self.tG = 0
-        self._fake = None
+        self._fake = [None, None]     # two persistent fake batches: the one in use and the prefetched next one
+        self._fake_cur = 0
+        self._prefetched = None       # dict(z, labels, done event) of the fake batch the last critic_step prepared
+        self._stream = None           # non-blocking stream full_step runs on (see full_step)
         self.last: Dict[str, torch.Tensor] = {}
 
     # ------------------------------------------------------------------ updates
@@ -61,30 +64,58 @@ class WGANGPTrainer:
         self.comm.allreduce(eng.grads.flat)
         ops.adam(eng.params.flat, eng.grads.flat, m, v, self.lr, self.b1, self.b2, self.eps, step)
 
+    def _fake_buf(self, which: int, B: int) -> torch.Tensor:
+        # persistent output buffers: stable pointers let the grouped-GEMM problem table be reused
+        if self._fake[which] is None or self._fake[which].shape[0] != B:
+            self._fake[which] = torch.empty(B, self.L, self.V, device=self.device)
+        return self._fake[which]
+
     def critic_step(self, tokens: torch.Tensor, labels: torch.Tensor, lengths: torch.Tensor, wsum: float,
                     z: Optional[torch.Tensor] = None, U: Optional[torch.Tensor] = None,
                     alpha: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
-                    update: bool = True):
+                    update: bool = True, next_batch=None):
         """tokens int32 [B,T], labels int64 [B], lengths int32 [B]: device tensors of this rank's shard.
         wsum: global sum of class weights.  Noise defaults to fresh device draws.
+        next_batch: optional dict(labels=..., z=..., U=...) of the NEXT critic_step (same batch size,
+        generator unchanged in between): its fake batch is generated on the second stream beside this
+        step's second-order sweeps and tail, and the next call picks it up.
         Returns the loss parts (device tensors; nothing synchronises)."""
         B, T = tokens.shape
         dev = self.device
         n_global = B * self.comm.world
-        if z is None:
-            z = torch.randn(B, LATENT, device=dev)
+        pre = self._prefetched
+        self._prefetched = None
+        if pre is not None and pre["labels"] is labels and (z is None or z is pre["z"]):
+            z, fake = pre["z"], self._fake_buf(self._fake_cur, B)
+            torch.cuda.current_stream().wait_event(pre["done"])
+        else:
+            if pre is not None:
+                torch.cuda.current_stream().wait_event(pre["done"])     # keep the generator's buffer updates ordered
+            if z is None:
+                z = torch.randn(B, LATENT, device=dev)
+            fake = self.G.forward(z, labels, U, self.tau, self.hard, training=True, save=False,
+                                  out=self._fake_buf(self._fake_cur, B))    # .detach(): no graph is kept
         if alpha is None:
             alpha = torch.rand(B, device=dev)
-        # persistent output buffer: stable pointers let the grouped-GEMM problem table be reused
-        if self._fake is None or self._fake.shape[0] != B:
-            self._fake = torch.empty(B, self.L, self.V, device=dev)
-        fake = self.G.forward(z, labels, U, self.tau, self.hard, training=True, save=False,
-                              out=self._fake)                               # .detach(): no graph is kept
         Tw = max(T, self.L)
         if mask is None and self.drop_rate > 0.0:
             mask = dropout_mask(3 * B * Tw, self.drop_rate, dev)
+        prefetch = None
+        if next_batch is not None and self.D.overlap and self.comm.world == 1:
+            nz = next_batch.get("z")
+            nxt = dict(labels=next_batch["labels"], z=nz if nz is not None else torch.randn(B, LATENT, device=dev),
+                       done=torch.cuda.Event())
+            other = self._fake_buf(self._fake_cur ^ 1, B)
+
+            def prefetch():
+                self.G.forward(nxt["z"], nxt["labels"], next_batch.get("U"), self.tau, self.hard, training=True,
+                               save=False, out=other)
+                nxt["done"].record()
         losses, pen = critic_iteration(self.D, tokens, lengths, labels, fake, alpha.reshape(-1).contiguous(),
-                                       self.lambda_gp, n_global, 1.0 / wsum, mask, CLASS_W)
+                                       self.lambda_gp, n_global, 1.0 / wsum, mask, CLASS_W, prefetch=prefetch)
+        if prefetch is not None:
+            self._prefetched = nxt
+            self._fake_cur ^= 1
         if update:
             self.tD += 1
             self._adam(self.D, self.mD, self.vD, self.tD)
@@ -106,6 +137,9 @@ class WGANGPTrainer:
         labels = self.last["labels"] if labels is None else labels
         z = self.last["z"] if z is None else z
         wsum = self.last["wsum"] if wsum is None else wsum
+        if self._prefetched is not None:          # a prefetched forward nobody consumed: stay ordered behind it
+            torch.cuda.current_stream().wait_event(self._prefetched["done"])
+            self._prefetched = None
         B = z.shape[0]
         n_global = B * self.comm.world
         fake = self.G.forward(z, labels, U, self.tau, self.hard, training=True, save=True)
@@ -128,10 +162,28 @@ class WGANGPTrainer:
     # ------------------------------------------------------------------ the full step
     def full_step(self, batches, noises=None):
         """batches: n_critic device batches (tokens i32, labels i64, lengths i32, wsum).  Generator
-        update after the first batch's critic update (i % n_critic == 0, wgan_gp.py:323)."""
-        for i, (tokens, labels, lengths, wsum) in enumerate(batches):
-            nz = noises[i] if noises is not None else {}
-            self.critic_step(tokens, labels, lengths, wsum, nz.get("z"), nz.get("U"), nz.get("alpha"),
-                             nz.get("mask"))
-            if i % self.n_critic == 0:
-                self.generator_step(U=nz.get("U2"), mask=nz.get("mask_g"))
+        update after the first batch's critic update (i % n_critic == 0, wgan_gp.py:323).
+
+        The step runs on a non-blocking stream of the trainer (the caller's stream waits for it on
+        return): the critic's CU-masked second stream is a blocking stream and would otherwise
+        synchronise with every launch when the caller sits on the NULL stream.  While the generator
+        stays fixed (between two generator updates) the next batch's fake sequences are prefetched
+        beside the current batch's second-order sweeps."""
+        cur = torch.cuda.current_stream()
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=self.device)
+        own = self._stream if (self.D.overlap and cur.cuda_stream == 0) else cur
+        own.wait_stream(cur)
+        with torch.cuda.stream(own):
+            n = len(batches)
+            for i, (tokens, labels, lengths, wsum) in enumerate(batches):
+                nz = noises[i] if noises is not None else {}
+                nxt = None
+                if i + 1 < n and i % self.n_critic != 0 and batches[i + 1][0].shape[0] == tokens.shape[0]:
+                    nn_ = noises[i + 1] if noises is not None else {}
+                    nxt = dict(labels=batches[i + 1][1], z=nn_.get("z"), U=nn_.get("U"))
+                self.critic_step(tokens, labels, lengths, wsum, nz.get("z"), nz.get("U"), nz.get("alpha"),
+                                 nz.get("mask"), next_batch=nxt)
+                if i % self.n_critic == 0:
+                    self.generator_step(U=nz.get("U2"), mask=nz.get("mask_g"))
+        cur.wait_stream(own)

@@ -159,3 +159,45 @@ def test_full_size_iteration_matches_reference_golden(golden, tag):
         else:
             assert_close(v.cpu().norm(), G[f"{tag}.G.grad_norm.{n}"], 2e-3, f"G grad norm {n}")
             assert_close(v.cpu().reshape(-1)[:4096], G[f"{tag}.G.grad_head.{n}"], 2e-3, f"G grad head {n}")
+
+
+def test_full_step_streams_and_prefetch_are_bit_exact():
+    """full_step (own stream, CU-masked second stream beside the second-order sweeps, next fake batch
+    prefetched) must give exactly the bits of the same launches issued one after the other on one
+    stream: same kernels, same split-K slabs, only the schedule differs."""
+    from s2g.trainer import WGANGPTrainer
+    Tf, B, T = 24, 8, 32
+    pg, pd = common.generator_params(901, 175, Tf), common.critic_params(902, scale=1.5)
+    batches = [dev_batch(*common.batch(910 + i, B, T, min_len=3)) for i in range(5)]
+    noises = []
+    for i in range(5):
+        nz = {n: v.to(DEV) for n, v in common.noise(920 + i, B, Tf).items()}
+        nz["alpha"] = nz["alpha"].view(-1).contiguous()
+        nz["mask"] = (torch.rand(3 * B * T, 52, generator=common.gen(930 + i)) > 0.3).float().div(0.7).to(DEV)
+        noises.append(nz)
+    mask_g = (torch.rand(B * Tf, 52, generator=common.gen(940)) > 0.3).float().div(0.7).to(DEV)
+    noises[0]["mask_g"] = mask_g
+
+    serial = WGANGPTrainer(175, Tf, DEV, drop_rate=0.3)
+    serial.G.load(pg); serial.D.load(pd)
+    serial.D.overlap = False
+    for i, (tok, lab, ln, wsum) in enumerate(batches):
+        nz = noises[i]
+        serial.critic_step(tok, lab, ln, wsum, nz["z"], nz["U"], nz["alpha"], nz["mask"])
+        if i == 0:
+            serial.generator_step(U=nz["U2"], mask=mask_g)
+
+    fused = WGANGPTrainer(175, Tf, DEV, drop_rate=0.3)
+    fused.G.load(pg); fused.D.load(pd)
+    fused.full_step(batches, noises)
+    torch.cuda.synchronize()
+    if fused.D._side is False:
+        pytest.skip("the runtime refused the CU-masked stream: nothing overlaps on this box")
+    assert fused.D._side is not None, "full_step did not take the overlapped path"
+    for n, v in serial.D.params.views.items():
+        assert torch.equal(v, fused.D.params.views[n]), f"critic {n}"
+    for n, v in serial.G.params.views.items():
+        assert torch.equal(v, fused.G.params.views[n]), f"generator {n}"
+    for b, v in serial.G.buffers.items():
+        assert torch.equal(v, fused.G.buffers[b]), b
+    assert torch.equal(serial.last["d_parts"], fused.last["d_parts"])
