@@ -65,9 +65,10 @@ typedef struct S2GGemm {
 } S2GGemm;
 int s2g_gemm_f32(const S2GGemm* args, int nsplit, void* stream);
 /* nprob problems in ONE launch.  table_dev / prefix_dev are DEVICE arrays: S2GGemm[nprob] (every
- * problem of the weight-gradient shape: A = [rows, M] with sam == 1, sak % 4 == 0 and a 16-byte
- * aligned base, kchunk > 0 set by the caller, no bias / act / accumulate) and int[nprob + 1] block
- * prefix sums; problem p owns ceil(N/64) * ceil(M/128) * nsplit_p blocks. */
+ * problem of the weight-gradient shape: A = [rows, M] with sam == 1, M % 4 == 0, M <= 256,
+ * sak % 4 == 0 and a 16-byte aligned base, kchunk > 0 set by the caller, no bias / act /
+ * accumulate) and int[nprob + 1] block prefix sums; problem p owns ceil(N/64) * nsplit_p blocks,
+ * each computing all M rows of 64 columns over one K-chunk. */
 int s2g_gemm_grouped(const S2GGemm* table_dev, const int* prefix_dev, int nprob, int total_blocks, void* stream);
 int s2g_reduce_slabs(const float* slabs, long slab, int nslab, int rows, int cols, float* out,
                      int permute_rows, int accumulate, float scale, void* stream);
@@ -143,6 +144,9 @@ int s2g_embed_mul(const float* z, const long long* labels, const float* emb, flo
 int s2g_embed_mul_bwd(const float* z, const long long* labels, const float* dout, float* demb, int B, int D,
                       int n_classes, void* stream);
 int s2g_lrelu_bwd(const float* y, float* dy, long n, void* stream);
+/* inter-layer dropout of nn.LSTM(175, 50, 2, dropout=p) in train mode (wgan_gp.py:189): uniform draws
+ * u[rows][52] -> multiplier (u >= p) / (1 - p) in place, columns 50 and 51 (row padding) -> 0 */
+int s2g_dropout_mask(float* u, long rows, float p, void* stream);
 int s2g_bn_stats(const float* x, float* stats, int B, int F, void* stream);
 int s2g_bn_lrelu_apply(const float* x, const float* stats, float n_global, const float* gamma,
                        const float* beta, float* run_mean, float* run_var, float eps, float momentum,

@@ -33,6 +33,21 @@ extern "C" __global__ void s2g_k_lrelu_bwd(const float* __restrict__ y, float* _
   if (i < n) dy[i] = y[i] > 0.0f ? dy[i] : 0.2f * dy[i];
 }
 
+// Inter-layer dropout multiplier of nn.LSTM(dropout=p) in train mode (wgan_gp.py:189): from uniform
+// draws u[rows][52] to m = (u >= p) / (1 - p) in place; columns 50, 51 are row padding and become 0.
+// One float4 (= 4 columns of one row, 52 % 4 == 0) per thread.
+extern "C" __global__ void s2g_k_dropout_mask(float* __restrict__ u, long n4, float p, float keep_scale) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  float4 v = reinterpret_cast<float4*>(u)[i];
+  const int c = (int)(i % (S2G_MASKW / 4)) * 4;
+  v.x = (v.x >= p) ? keep_scale : 0.0f;
+  v.y = (v.y >= p) ? keep_scale : 0.0f;
+  v.z = (c + 2 < S2G_H && v.z >= p) ? keep_scale : 0.0f;
+  v.w = (c + 3 < S2G_H && v.w >= p) ? keep_scale : 0.0f;
+  reinterpret_cast<float4*>(u)[i] = v;
+}
+
 // BatchNorm1d over the batch axis, split in two so data-parallel ranks can all-reduce the
 // per-feature sums in between (SyncBN):   stats[0][f] = sum_b x, stats[1][f] = sum_b x^2.
 extern "C" __global__ void s2g_k_bn_stats(const float* __restrict__ x, float* __restrict__ stats, int B, int F) {

@@ -217,6 +217,12 @@ int s2g_lrelu_bwd(const float* y, float* dy, long n, void* stream) {
   hipLaunchKernelGGL(s2g_k_lrelu_bwd, dim3(cdiv(n, 256)), dim3(256), 0, ST(stream), y, dy, n);
   return LAUNCH_OK();
 }
+int s2g_dropout_mask(float* u, long rows, float p, void* stream) {
+  if (!u || rows <= 0 || !(p >= 0.0f) || !(p < 1.0f) || ((uintptr_t)u & 15)) return -1;
+  const long n4 = rows * (S2G_MASKW / 4);
+  hipLaunchKernelGGL(s2g_k_dropout_mask, dim3(cdiv(n4, 256)), dim3(256), 0, ST(stream), u, n4, p, 1.0f / (1.0f - p));
+  return LAUNCH_OK();
+}
 int s2g_bn_stats(const float* x, float* stats, int B, int F, void* stream) {
   if (!x || !stats || B <= 0 || F <= 0) return -1;
   hipLaunchKernelGGL(s2g_k_bn_stats, dim3(cdiv(F, 64)), dim3(64), 0, ST(stream), x, stats, B, F);

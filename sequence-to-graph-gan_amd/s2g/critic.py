@@ -420,30 +420,50 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
     mrel = ptr(mask, r_int * MASKW) if mask is not None else None
 
     sc = eng.scratch
+
+    def second_order_sums():
+        """bias gradients of the penalty term and its part of fc.weight[0] = sum_b hdot1_final(b)"""
+        ops.colsum(a0, n3, G4, G4, g["lstm.bias_ih_l0"], sc, permute_rows=True, accumulate=True)
+        ops.colsum(a1, n3, G4, G4, g["lstm.bias_ih_l1"], sc, permute_rows=True, accumulate=True)
+        g["lstm.bias_hh_l0"].copy_(g["lstm.bias_ih_l0"])
+        g["lstm.bias_hh_l1"].copy_(g["lstm.bias_ih_l1"])
+        ops.colsum(ws["hdotT"], B, H, H, g["fc.weight"][0], sc, accumulate=True)
+
     side = eng.side() if eng.overlap else None
     if side is not None:
-        # stream_c: project, sweep C, sweep D (B workgroups on the reserved quarter of the CUs)
+        # stream_c: project, sweep C, sweep D (B workgroups on the reserved quarter of the CUs), then the
+        #           second-order column sums, which run beside the last products on the caller's stream
         # stream2 : products of phase 0 beside sweep C, products of phase 1 beside sweep D
         stream2, stream_c, fork, after_c, join, join_c, sc2 = side
+        cur = torch.cuda.current_stream()
         fork.record()
+        with torch.cuda.stream(stream2):
+            stream2.wait_event(fork)
+            first_order(sc2)
         with torch.cuda.stream(stream_c):
             stream_c.wait_event(fork)
             eng.project(ws["G"], ws["Pv"])
             eng.timed("s2g_k_lstm2_tangent", lambda: eng.sweep_tangent(ws, drel, B, mrel, r_int))
             after_c.record()
-            eng.timed("s2g_k_lstm2_bwd2", lambda: eng.sweep_bwd2(ws, drel, B, Tw, mrel, r_int))
-            join_c.record()
         with torch.cuda.stream(stream2):
-            stream2.wait_event(fork)
-            first_order(sc2)
             stream2.wait_event(after_c)
             _wgrad_launch(eng, built, 1)
             join.record()
             if prefetch is not None:
                 prefetch()          # not part of the join: it may run on beside this iteration's tail
-        cur = torch.cuda.current_stream()
-        cur.wait_event(join_c)
+        with torch.cuda.stream(stream_c):
+            after_d = torch.cuda.Event()
+            eng.timed("s2g_k_lstm2_bwd2", lambda: eng.sweep_bwd2(ws, drel, B, Tw, mrel, r_int))
+            after_d.record()
+        cur.wait_event(after_d)
         cur.wait_event(join)
+        _wgrad_launch(eng, built, 2)
+        with torch.cuda.stream(stream_c):
+            stream_c.wait_event(join)        # the first-order bias sums these accumulate onto
+            second_order_sums()
+            join_c.record()
+        _wgrad_reduce(eng, built)
+        cur.wait_event(join_c)
     else:
         eng.project(ws["G"], ws["Pv"])
         eng.timed("s2g_k_lstm2_tangent", lambda: eng.sweep_tangent(ws, drel, B, mrel, r_int))
@@ -452,14 +472,9 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         _wgrad_launch(eng, built, 1)
         if prefetch is not None:
             prefetch()
-    _wgrad_launch(eng, built, 2)
-    _wgrad_reduce(eng, built)
-    ops.colsum(a0, n3, G4, G4, g["lstm.bias_ih_l0"], sc, permute_rows=True, accumulate=True)
-    ops.colsum(a1, n3, G4, G4, g["lstm.bias_ih_l1"], sc, permute_rows=True, accumulate=True)
-    g["lstm.bias_hh_l0"].copy_(g["lstm.bias_ih_l0"])
-    g["lstm.bias_hh_l1"].copy_(g["lstm.bias_ih_l1"])
-    # second-order part of fc.weight[0]: sum_b hdot1_final(b)
-    ops.colsum(ws["hdotT"], B, H, H, g["fc.weight"][0], sc, accumulate=True)
+        _wgrad_launch(eng, built, 2)
+        _wgrad_reduce(eng, built)
+        second_order_sums()
     return ws["losses"], ws["pen"]
 
 

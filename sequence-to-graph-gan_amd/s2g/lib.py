@@ -57,6 +57,7 @@ SIGNATURES = {
     "s2g_embed_mul": [P, P, P, P, I, I, P],
     "s2g_embed_mul_bwd": [P, P, P, P, I, I, I, P],
     "s2g_lrelu_bwd": [P, P, L, P],
+    "s2g_dropout_mask": [P, L, F, P],
     "s2g_bn_stats": [P, P, I, I, P],
     "s2g_bn_lrelu_apply": [P, P, F, P, P, P, P, F, F, I, P, P, P, I, I, P],
     "s2g_bn_lrelu_bwd_stats": [P, P, P, P, I, I, P],

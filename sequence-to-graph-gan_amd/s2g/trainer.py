@@ -12,8 +12,8 @@ import torch
 from . import ops
 from .critic import CriticEngine, critic_forward_backward_fake, critic_iteration
 from .generator import LATENT, GeneratorEngine, NoComm
-from .lib import S2GError
-from .ops import MASKW, H
+from .lib import S2GError, call
+from .ops import MASKW, H, ptr, stream_ptr
 
 CLASS_W = (1.0, 2.0)      # wgan_gp.py:267
 
@@ -29,8 +29,8 @@ def dropout_mask(rows: int, p: float, device) -> Optional[torch.Tensor]:
     in train mode (wgan_gp.py:189); columns 50,51 are padding."""
     if p <= 0.0:
         return None
-    m = (torch.rand(rows, MASKW, device=device) >= p).to(torch.float32) / (1.0 - p)
-    m[:, H:] = 0.0
+    m = torch.rand(rows, MASKW, device=device)          # the draw; the thresholding is one libs2g kernel
+    call("s2g_dropout_mask", ptr(m), rows, float(p), stream_ptr())
     return m
 
 
