@@ -135,6 +135,11 @@ int s2g_gp_interp_dense(const float* real, const int* lengths, const float* fake
  * g_b <- upstream * 2 (|g_b| - 1) / (n_batch |g_b|) * g_b */
 int s2g_gp_norm_penalty(float* g, int B, long per_sample, float upstream, float n_batch, float* pen,
                         float* norms, int scale_in_place, void* stream);
+/* the same penalty from the layer-0 gate gradients delta [rows,200] and pv = delta (W_ih0 W_ih0^T):
+ * |g_b|^2 = sum_t delta_t . pv_t, so the 175-wide gradients.view(B,-1) of wgan_gp.py:255 need not
+ * exist yet; pv_b <- coef_b * pv_b in place (the projected direction the tangent sweep consumes) */
+int s2g_gp_norm_penalty_proj(const float* delta, float* pv, int B, long per_sample, float upstream,
+                             float n_batch, float* pen, float* norms, void* stream);
 int s2g_gp_scale(const float* g, const float* norms, const float* upstream, float n_batch, long per_sample,
                  float* v, int B, void* stream);
 

@@ -249,6 +249,48 @@ extern "C" __global__ __launch_bounds__(1024) void s2g_k_gp_norm_penalty(float* 
   }
 }
 
+// The same reduction without materialising g first.  With g_t = W_ih0^T delta_t (delta = gate
+// gradient of layer 0, rows of sample b) and pv_t = (W_ih0 W_ih0^T) delta_t:
+//   |g_b|^2 = sum_t delta_t . pv_t        and        W_ih0 (coef_b g_t) = coef_b pv_t,
+// so one [rows,200]x[200,200] product gives both the norm and, scaled in place here, the projected
+// direction the tangent sweep starts from; the 175-wide g itself is only needed later (for one
+// weight-gradient product) and is computed off the critical path.
+extern "C" __global__ __launch_bounds__(1024) void s2g_k_gp_norm_penalty_proj(
+    const float* __restrict__ delta, float* __restrict__ pv, long per_sample, float upstream, float n_batch,
+    float* __restrict__ pen, float* __restrict__ norms) {
+  __shared__ float red[16];
+  __shared__ float coef_s;
+  const int b = blockIdx.x;
+  const float4* d4 = reinterpret_cast<const float4*>(delta + (long)b * per_sample);
+  float4* p4 = reinterpret_cast<float4*>(pv + (long)b * per_sample);
+  const long n4 = per_sample >> 2;
+  float s0 = 0.0f, s1 = 0.0f;
+  for (long i = threadIdx.x; i < n4; i += blockDim.x) {
+    const float4 d = d4[i], p = p4[i];
+    s0 = fmaf(d.x, p.x, s0); s1 = fmaf(d.y, p.y, s1); s0 = fmaf(d.z, p.z, s0); s1 = fmaf(d.w, p.w, s1);
+  }
+  float s = row16_sum(s0 + s1);
+  s += __shfl_xor(s, 16);
+  s += __shfl_xor(s, 32);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.0f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += red[w];
+    const float nb = sqrtf(fmaxf(tot, 0.0f));
+    pen[b] = (nb - 1.0f) * (nb - 1.0f);
+    if (norms) norms[b] = nb;
+    coef_s = nb > 0.0f ? upstream * 2.0f * (nb - 1.0f) / (n_batch * nb) : 0.0f;
+  }
+  __syncthreads();
+  const float c = coef_s;
+  for (long i = threadIdx.x; i < n4; i += blockDim.x) {
+    float4 p = p4[i];
+    p.x *= c; p.y *= c; p.z *= c; p.w *= c;
+    p4[i] = p;
+  }
+}
+
 // v_b = coef_b * g_b with coef_b = upstream * 2 (n_b - 1) / (n_batch * n_b), out of place
 // (used when the upstream gradient only becomes known in a later backward call).
 extern "C" __global__ void s2g_k_gp_scale(const float* __restrict__ g, const float* __restrict__ norms,

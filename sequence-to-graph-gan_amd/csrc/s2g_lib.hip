@@ -189,6 +189,14 @@ int s2g_gp_norm_penalty(float* g, int B, long per_sample, float upstream, float 
                      pen, norms, scale_in_place);
   return LAUNCH_OK();
 }
+int s2g_gp_norm_penalty_proj(const float* delta, float* pv, int B, long per_sample, float upstream, float n_batch,
+                             float* pen, float* norms, void* stream) {
+  if (!delta || !pv || !pen || B <= 0 || per_sample <= 0 || (per_sample & 3) || !(n_batch > 0.0f)) return -1;
+  if ((((uintptr_t)delta) | ((uintptr_t)pv)) & 15) return -1;
+  hipLaunchKernelGGL(s2g_k_gp_norm_penalty_proj, dim3(B), dim3(1024), 0, ST(stream), delta, pv, per_sample, upstream,
+                     n_batch, pen, norms);
+  return LAUNCH_OK();
+}
 int s2g_gp_scale(const float* g, const float* norms, const float* upstream, float n_batch, long per_sample,
                  float* v, int B, void* stream) {
   if (!g || !norms || !upstream || !v || B <= 0 || per_sample <= 0) return -1;

@@ -57,6 +57,8 @@ class CriticEngine:
         self.W0p = torch.empty(G4, vocab, device=device)
         self.b0 = torch.empty(G4, device=device)
         self.b1 = torch.empty(G4, device=device)
+        self.M2 = torch.empty(G4, G4, device=device)
+        self._scalars = {}
         self.scratch = ops.Scratch(device)
         self.timed_events = None      # dict kernel name -> [(start, end) HIP event pairs] (benchmark hook)
         self._gemm_tables = {}        # cached device-side problem tables of the grouped weight-gradient GEMM
@@ -77,6 +79,16 @@ class CriticEngine:
         call("s2g_pack_critic", ptr(p["lstm.weight_ih_l0"]), ptr(p["lstm.bias_ih_l0"]), ptr(p["lstm.bias_hh_l0"]),
              ptr(p["lstm.bias_ih_l1"]), ptr(p["lstm.bias_hh_l1"]), ptr(self.WT0), ptr(self.W0p), ptr(self.b0),
              ptr(self.b1), self.V, stream_ptr())
+        # M2 = W_ih0 W_ih0^T (internal gate order): maps layer-0 gate gradients straight to the projected
+        # input gradient (critic_iteration)
+        ops.gemm_raw(ptr(self.W0p), self.V, 1, ptr(self.WT0), G4, 1, ptr(self.M2), G4, G4, G4, self.V)
+
+    def device_scalar(self, value: float) -> torch.Tensor:
+        """A cached 1-element device tensor holding `value` (kernel arguments read on the device)."""
+        t = self._scalars.get(value)
+        if t is None:
+            t = self._scalars[value] = torch.full((1,), value, dtype=torch.float32, device=self.device)
+        return t
 
     # ------------------------------------------------------------------ workspaces
     def workspace(self, nseq: int, Tw: int, so_seqs: int) -> Dict[str, torch.Tensor]:
@@ -376,11 +388,16 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
     call("s2g_head_bwd_w", ptr(ws["dout"]), ptr(ws["hT"]), ptr(g["fc.weight"]), ptr(g["fc.bias"]), 2 * B, 3, 0, st)
     # sweep B on 3B sequences (the interp third with d(out) = e0 and stored adjoints)
     eng.timed("s2g_k_lstm2_bwd", lambda: eng.sweep_bwd(ws, dptr, 3 * B, Tw, mask, adj_seq0=2 * B))
-    # input gradient of the interp third, its norm, the penalty and the direction v (in place)
+    # Penalty of the interp third (wgan_gp.py:247-256).  With g_t = W_ih0^T delta0_t the norm is
+    # |g_b|^2 = sum_t delta0_t . (M2 delta0_t), M2 = W_ih0 W_ih0^T, and the projected direction the
+    # tangent sweep consumes is coef_b * M2 delta0_t: one 200x200 product on the critical path.  The
+    # 175-wide direction v = coef_b * g itself feeds one weight-gradient product only and is built
+    # beside sweep C (first_order below).
     r_int = 2 * B * Tw
-    ops.gemm_raw(ptr(ws["delta0"], r_int * G4), G4, 1, ptr(eng.W0p), V, 1, ptr(ws["G"]), V, B * Tw, V, G4)
-    call("s2g_gp_norm_penalty", ptr(ws["G"]), B, Tw * V, float(lambda_gp), float(n_global), ptr(ws["pen"]),
-         ptr(ws["norms"]), 1, st)
+    ops.gemm_raw(ptr(ws["delta0"], r_int * G4), G4, 1, ptr(eng.M2), G4, 1, ptr(ws["Pv"]), G4, B * Tw, G4, G4)
+    call("s2g_gp_norm_penalty_proj", ptr(ws["delta0"], r_int * G4), ptr(ws["Pv"]), B, Tw * G4, float(lambda_gp),
+         float(n_global), ptr(ws["pen"]), ptr(ws["norms"]), st)
+    lam = eng.device_scalar(float(lambda_gp))
     d0, d1, c0, c1 = ws["delta0"], ws["delta1"], ws["cell0"], ws["cell1"]
     a0, a1, cd0, cd1 = ws["abar0"], ws["abar1"], ws["celld0"], ws["celld1"]
     oi = r_int * G4
@@ -410,6 +427,9 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         """Everything that needs sweeps A and B only: operands of the products, their phase-0 part, the
         first-order bias gradients."""
         s_ = stream_ptr()
+        # v = coef_b * (delta0 W_ih0): the direction of the penalty's second-order term in input space
+        ops.gemm_raw(ptr(ws["delta0"], r_int * G4), G4, 1, ptr(eng.W0p), V, 1, ptr(ws["G"]), V, B * Tw, V, G4)
+        call("s2g_gp_scale", ptr(ws["G"]), ptr(ws["norms"]), ptr(lam), float(n_global), Tw * V, ptr(ws["G"]), B, s_)
         call("s2g_one_hot", ptr(tokens), ptr(lengths), T, ptr(ws["xreal"]), B * T, V, s_)
         call("s2g_gp_interp", ptr(tokens), ptr(lengths), ptr(fake), ptr(alpha), B, T, Tf, V, ptr(ws["xhat"]), s_)
         _wgrad_launch(eng, built, 0)
@@ -431,7 +451,7 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
 
     side = eng.side() if eng.overlap else None
     if side is not None:
-        # stream_c: project, sweep C, sweep D (B workgroups on the reserved quarter of the CUs), then the
+        # stream_c: sweep C, sweep D (B workgroups on the reserved quarter of the CUs), then the
         #           second-order column sums, which run beside the last products on the caller's stream
         # stream2 : products of phase 0 beside sweep C, products of phase 1 beside sweep D
         stream2, stream_c, fork, after_c, join, join_c, sc2 = side
@@ -442,7 +462,6 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
             first_order(sc2)
         with torch.cuda.stream(stream_c):
             stream_c.wait_event(fork)
-            eng.project(ws["G"], ws["Pv"])
             eng.timed("s2g_k_lstm2_tangent", lambda: eng.sweep_tangent(ws, drel, B, mrel, r_int))
             after_c.record()
         with torch.cuda.stream(stream2):
@@ -465,7 +484,6 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         _wgrad_reduce(eng, built)
         cur.wait_event(join_c)
     else:
-        eng.project(ws["G"], ws["Pv"])
         eng.timed("s2g_k_lstm2_tangent", lambda: eng.sweep_tangent(ws, drel, B, mrel, r_int))
         eng.timed("s2g_k_lstm2_bwd2", lambda: eng.sweep_bwd2(ws, drel, B, Tw, mrel, r_int))
         first_order(sc)

@@ -53,6 +53,7 @@ SIGNATURES = {
     "s2g_gp_interp": [P, P, P, P, I, I, I, I, P, P],
     "s2g_gp_interp_dense": [P, P, P, P, I, I, I, I, P, P],
     "s2g_gp_norm_penalty": [P, I, L, F, F, P, P, I, P],
+    "s2g_gp_norm_penalty_proj": [P, P, I, L, F, F, P, P, P],
     "s2g_gp_scale": [P, P, P, F, L, P, I, P],
     "s2g_embed_mul": [P, P, P, P, I, I, P],
     "s2g_embed_mul_bwd": [P, P, P, P, I, I, I, P],
