@@ -26,12 +26,19 @@ def per_kernel(d, counter):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()
         tot[k] += float(r["Counter_Value"])
         cnt[k] += 1
-    return {k: tot[k] / cnt[k] for k in tot}
+    return {k: tot[k] / cnt[k] for k in tot}, dict(cnt)
 
 
 def main():
     fetch_dir, write_dir, tag = sys.argv[1:4]
-    fe, wr = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    (fe, nfe), (wr, nwr) = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
+    # per-kernel summaries of the two passes (the raw per-dispatch CSVs are ~0.5 MB each)
+    for name, counter, vals, cnts in (("fetch", "FETCH_SIZE", fe, nfe), ("write", "WRITE_SIZE", wr, nwr)):
+        with open(os.path.join(root, "profiles", f"{tag}_pmc_{name}.csv"), "w") as f:
+            f.write(f"Kernel_Name,Launches,Mean_{counter}_KiB\n")
+            for k in sorted(vals, key=lambda k: -vals[k] * cnts[k]):
+                f.write(f"\"{k}\",{cnts[k]},{vals[k]:.1f}\n")
     out = {}
     for k in sorted(set(fe) | set(wr)):
         if not k.startswith("s2g_k_"):
