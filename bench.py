@@ -173,7 +173,10 @@ def main():
             with open(pmc) as f:
                 t = json.load(f).get(dom)
             if t:
-                traffic, traffic_src = t["bytes_per_launch"], t["source"]
+                # avg_launch_ms of a kernel launched several times per iteration is the sum over those
+                # launches, so the traffic is scaled the same way
+                n_tags = sum(1 for tag in ev if tag.split("#")[0] == dom)
+                traffic, traffic_src = t["bytes_per_launch"] * n_tags, t["source"]
         line = {
             "metric": "WGAN-GP train sequences/sec at V=175 L=512", "value": seqs / dt, "unit": "sequences/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,

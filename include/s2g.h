@@ -72,6 +72,13 @@ int s2g_gemm_f32(const S2GGemm* args, int nsplit, void* stream);
 int s2g_gemm_grouped(const S2GGemm* table_dev, const int* prefix_dev, int nprob, int total_blocks, void* stream);
 int s2g_reduce_slabs(const float* slabs, long slab, int nslab, int rows, int cols, float* out,
                      int permute_rows, int accumulate, float scale, void* stream);
+/* up to 8 such reductions in one launch; `jobs` is a HOST array (copied into the kernel arguments) */
+typedef struct S2GReduce {
+  const float* slabs; long slab; float* out;
+  int nslab, rows, cols;
+} S2GReduce;
+int s2g_reduce_slabs_multi(const S2GReduce* jobs, int njobs, int permute_rows, int accumulate, float scale,
+                           void* stream);
 /* part[chunk][c] = sum over a chunk of rows of X[r*ld + c]; nchunk = ceil(rows / rows_per_chunk). */
 int s2g_colsum(const float* X, long ld, long rows, int cols, float* part, long rows_per_chunk, void* stream);
 

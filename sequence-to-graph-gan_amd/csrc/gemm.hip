@@ -410,13 +410,12 @@ extern "C" __global__ __launch_bounds__(256) void s2g_k_gemm_grouped(const GemmA
 // permute_rows, identity otherwise.  A block of 4 waves owns 64 consecutive output elements; wave w
 // sums slabs w, w+4, w+8, ... (four loads in flight per thread), the partial sums meet in LDS.  The
 // summation order is fixed by (nslab), so results are reproducible run to run.
-extern "C" __global__ __launch_bounds__(256) void s2g_k_reduce_slabs(const float* __restrict__ slabs, long slab,
-                                                                     int nslab, int rows, int cols,
-                                                                     float* __restrict__ out, int permute_rows,
-                                                                     int accumulate, float scale) {
+__device__ __forceinline__ void reduce_slabs_block(const float* __restrict__ slabs, long slab, int nslab, int rows,
+                                                   int cols, float* __restrict__ out, int permute_rows,
+                                                   int accumulate, float scale, int block) {
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const long i = (long)blockIdx.x * 64 + lane;
+  const long i = (long)block * 64 + lane;
   const bool ok = i < (long)rows * cols;
   float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
   if (ok) {
@@ -436,6 +435,33 @@ extern "C" __global__ __launch_bounds__(256) void s2g_k_reduce_slabs(const float
   long o = (long)ro * cols + c;
   s *= scale;
   out[o] = accumulate ? out[o] + s : s;
+}
+
+extern "C" __global__ __launch_bounds__(256) void s2g_k_reduce_slabs(const float* __restrict__ slabs, long slab,
+                                                                     int nslab, int rows, int cols,
+                                                                     float* __restrict__ out, int permute_rows,
+                                                                     int accumulate, float scale) {
+  reduce_slabs_block(slabs, slab, nslab, rows, cols, out, permute_rows, accumulate, scale, blockIdx.x);
+}
+
+// Several independent reductions in one launch (the four weight gradients of a critic iteration):
+// job j owns blocks [first_block[j], first_block[j+1]).
+#define S2G_MAX_REDUCE_JOBS 8
+struct ReduceJob {
+  const float* slabs; long slab; float* out;
+  int nslab, rows, cols, first_block;
+};
+struct ReduceJobs {
+  ReduceJob j[S2G_MAX_REDUCE_JOBS];
+  int njobs;
+};
+extern "C" __global__ __launch_bounds__(256) void s2g_k_reduce_slabs_multi(ReduceJobs a, int permute_rows,
+                                                                           int accumulate, float scale) {
+  int k = 0;
+  while (k + 1 < a.njobs && (int)blockIdx.x >= a.j[k + 1].first_block) ++k;
+  const ReduceJob& q = a.j[k];
+  reduce_slabs_block(q.slabs, q.slab, q.nslab, q.rows, q.cols, q.out, permute_rows, accumulate, scale,
+                     blockIdx.x - q.first_block);
 }
 
 // column sums: out[perm(c)] (+)= scale * sum_r X[r][c], X row-major [rows, cols] with row stride ld.

@@ -62,6 +62,27 @@ int s2g_reduce_slabs(const float* slabs, long slab, int nslab, int rows, int col
   return LAUNCH_OK();
 }
 
+struct S2GReduce {      // mirrors include/s2g.h
+  const float* slabs; long slab; float* out;
+  int nslab, rows, cols;
+};
+int s2g_reduce_slabs_multi(const S2GReduce* jobs, int njobs, int permute_rows, int accumulate, float scale,
+                           void* stream) {
+  if (!jobs || njobs <= 0 || njobs > S2G_MAX_REDUCE_JOBS) return -1;
+  ReduceJobs a;
+  int blocks = 0;
+  for (int k = 0; k < njobs; ++k) {
+    const S2GReduce& q = jobs[k];
+    if (!q.slabs || !q.out || q.nslab <= 0 || q.rows <= 0 || q.cols <= 0) return -1;
+    if (permute_rows && q.rows != S2G_G) return -1;
+    a.j[k] = ReduceJob{q.slabs, q.slab, q.out, q.nslab, q.rows, q.cols, blocks};
+    blocks += (int)cdiv((long)q.rows * q.cols, 64);
+  }
+  a.njobs = njobs;
+  hipLaunchKernelGGL(s2g_k_reduce_slabs_multi, dim3(blocks), dim3(256), 0, ST(stream), a, permute_rows, accumulate,
+                     scale);
+  return LAUNCH_OK();
+}
 int s2g_colsum(const float* X, long ld, long rows, int cols, float* part, long rows_per_chunk, void* stream) {
   if (!X || !part || rows <= 0 || cols <= 0 || rows_per_chunk <= 0) return -1;
   hipLaunchKernelGGL(s2g_k_colsum, dim3(cdiv(cols, 64), cdiv(rows, rows_per_chunk)), dim3(256), 0, ST(stream), X,

@@ -327,10 +327,15 @@ def _wgrad_launch(eng: "CriticEngine", built, phase: int) -> None:
 
 
 def _wgrad_reduce(eng: "CriticEngine", built) -> None:
+    from .lib import S2GReduce
     _, job_slabs, slabs = built
-    for out, nsl, slab, base in job_slabs:
-        if nsl:
-            call("s2g_reduce_slabs", ptr(slabs, base), slab, nsl, G4, slab // G4, ptr(out), 1, 0, 1.0, stream_ptr())
+    live = [(out, nsl, slab, base) for out, nsl, slab, base in job_slabs if nsl]
+    for i in range(0, len(live), 8):                    # one launch per 8 parameters
+        part = live[i:i + 8]
+        arr = (S2GReduce * len(part))()
+        for k, (out, nsl, slab, base) in enumerate(part):
+            arr[k] = S2GReduce(ptr(slabs, base), slab, ptr(out), nsl, G4, slab // G4)
+        call("s2g_reduce_slabs_multi", arr, len(part), 1, 0, 1.0, stream_ptr())
 
 
 def _wgrad_grouped(eng: "CriticEngine", jobs, cache_key) -> None:
@@ -342,13 +347,15 @@ def _wgrad_grouped(eng: "CriticEngine", jobs, cache_key) -> None:
 
 def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Tensor, labels: torch.Tensor,
                      fake: torch.Tensor, alpha: torch.Tensor, lambda_gp: float, n_global: int, inv_wsum: float,
-                     mask: Optional[torch.Tensor] = None, class_w=(1.0, 2.0), prefetch=None):
+                     mask: Optional[torch.Tensor] = None, class_w=(1.0, 2.0), prefetch=None, idle=None):
     """One critic loss + gradient evaluation (wgan_gp.py:297-317) on the batch
     [real B | fake B | interp B], all three passes sharing each of the four sweeps.
 
     prefetch: optional callable launched on the second stream after this iteration's own work there
     (the trainer generates the next iteration's fake batch in it); it is NOT waited for here, the
     caller synchronises with whatever it enqueued.
+    idle: optional callable run on the caller's stream while it would otherwise wait for the
+    second-order sweeps (the trainer draws the next iteration's noise and dropout mask in it).
 
     tokens int32 [B,T] (zero padded), lengths int32 [B], labels int64 [B], fake fp32 [B,Tf,V],
     alpha fp32 [B] (the draw of wgan_gp.py:228), mask fp32 [3*B*Tw, 52] or None.
@@ -474,6 +481,8 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
             after_d = torch.cuda.Event()
             eng.timed("s2g_k_lstm2_bwd2", lambda: eng.sweep_bwd2(ws, drel, B, Tw, mrel, r_int))
             after_d.record()
+        if idle is not None:
+            idle()
         cur.wait_event(after_d)
         cur.wait_event(join)
         _wgrad_launch(eng, built, 2)
@@ -493,6 +502,8 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         _wgrad_launch(eng, built, 2)
         _wgrad_reduce(eng, built)
         second_order_sums()
+        if idle is not None:
+            idle()
     return ws["losses"], ws["pen"]
 
 

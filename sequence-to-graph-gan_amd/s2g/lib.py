@@ -28,6 +28,10 @@ class S2GGemm(ctypes.Structure):
                 ("a_seg", I), ("b_seg", I), ("shift", I), ("accumulate", I), ("act", I), ("alpha", F)]
 
 
+class S2GReduce(ctypes.Structure):
+    _fields_ = [("slabs", P), ("slab", L), ("out", P), ("nslab", I), ("rows", I), ("cols", I)]
+
+
 # name -> argument types (every function returns int and takes the stream last)
 SIGNATURES = {
     "s2g_version": [],
@@ -37,6 +41,7 @@ SIGNATURES = {
     "s2g_gemm_f32": [ctypes.POINTER(S2GGemm), I, P],
     "s2g_gemm_grouped": [P, P, I, I, P],
     "s2g_reduce_slabs": [P, L, I, I, I, P, I, I, F, P],
+    "s2g_reduce_slabs_multi": [P, I, I, I, F, P],
     "s2g_colsum": [P, L, L, I, P, L, P],
     "s2g_lstm2_fwd": [P, I, I] + [P] * 15,
     "s2g_lstm2_bwd": [P, I, I] + [P] * 13 + [I, I, P],

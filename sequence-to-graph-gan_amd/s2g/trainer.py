@@ -88,6 +88,10 @@ class WGANGPTrainer:
         if pre is not None and pre["labels"] is labels and (z is None or z is pre["z"]):
             z, fake = pre["z"], self._fake_buf(self._fake_cur, B)
             torch.cuda.current_stream().wait_event(pre["done"])
+            if alpha is None:
+                alpha = pre.get("alpha")
+            if mask is None and pre.get("mask") is not None and pre["mask"].shape[0] == 3 * B * max(T, self.L):
+                mask = pre["mask"]
         else:
             if pre is not None:
                 torch.cuda.current_stream().wait_event(pre["done"])     # keep the generator's buffer updates ordered
@@ -111,8 +115,18 @@ class WGANGPTrainer:
                 self.G.forward(nxt["z"], nxt["labels"], next_batch.get("U"), self.tau, self.hard, training=True,
                                save=False, out=other)
                 nxt["done"].record()
+
+            def idle():
+                # the next step's own draws, made while this stream waits for the second-order sweeps
+                if next_batch.get("alpha") is None:
+                    nxt["alpha"] = torch.rand(B, device=dev)
+                if next_batch.get("mask") is None and self.drop_rate > 0.0 and next_batch.get("T"):
+                    nxt["mask"] = dropout_mask(3 * B * max(next_batch["T"], self.L), self.drop_rate, dev)
+        else:
+            idle = None
         losses, pen = critic_iteration(self.D, tokens, lengths, labels, fake, alpha.reshape(-1).contiguous(),
-                                       self.lambda_gp, n_global, 1.0 / wsum, mask, CLASS_W, prefetch=prefetch)
+                                       self.lambda_gp, n_global, 1.0 / wsum, mask, CLASS_W, prefetch=prefetch,
+                                       idle=idle)
         if prefetch is not None:
             self._prefetched = nxt
             self._fake_cur ^= 1
@@ -181,7 +195,8 @@ class WGANGPTrainer:
                 nxt = None
                 if i + 1 < n and i % self.n_critic != 0 and batches[i + 1][0].shape[0] == tokens.shape[0]:
                     nn_ = noises[i + 1] if noises is not None else {}
-                    nxt = dict(labels=batches[i + 1][1], z=nn_.get("z"), U=nn_.get("U"))
+                    nxt = dict(labels=batches[i + 1][1], z=nn_.get("z"), U=nn_.get("U"), alpha=nn_.get("alpha"),
+                               mask=nn_.get("mask"), T=batches[i + 1][0].shape[1])
                 self.critic_step(tokens, labels, lengths, wsum, nz.get("z"), nz.get("U"), nz.get("alpha"),
                                  nz.get("mask"), next_batch=nxt)
                 if i % self.n_critic == 0:
