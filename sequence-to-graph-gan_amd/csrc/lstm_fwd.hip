@@ -42,15 +42,18 @@ __device__ __forceinline__ void load_w_half(const float* W, int u, int s, f2 wk[
   }
 }
 
-// pre-activations of gates (2s, 2s+1) of unit u = init + W . v; slice = this lane's 28-float slice
-__device__ __forceinline__ f2 matvec_half(const f2 wk[25], const f2 wx[25], const float* slice, f2 init) {
-  float v[28];
+// this lane's 28-float slice of an LDS state vector
+__device__ __forceinline__ void load_slice28(const float* slice, float v[28]) {
   const float4* p = reinterpret_cast<const float4*>(slice);
 #pragma unroll
   for (int i = 0; i < 7; ++i) {
     const float4 a = p[i];
     v[4 * i] = a.x; v[4 * i + 1] = a.y; v[4 * i + 2] = a.z; v[4 * i + 3] = a.w;
   }
+}
+
+// pre-activations of gates (2s, 2s+1) of unit u = init + W . v
+__device__ __forceinline__ f2 matvec_half(const f2 wk[25], const f2 wx[25], const float v[28], f2 init) {
   f2 ak = init, ax = {0.f, 0.f};
 #pragma unroll
   for (int k = 0; k < 25; ++k) {
@@ -204,65 +207,94 @@ extern "C" __global__ __launch_bounds__(FWD_THREADS) void s2g_k_lstm2_fwd(
 #pragma unroll
     for (int j = 0; j < PF; ++j) ISSUE_A(j, j, tok_lds[min(j, len - 1)])
     int tk = tok_lds[min(PF, len - 1)];      // token of the next step to prefetch, read one step early
+    // Order inside a step: the LDS reads of h_{t-1} go first (they head the step's critical path);
+    // their latency is filled with work that is off it -- the global stores of step t-1 (kept in
+    // registers for one step) and the refill of the ring slot step t-1 consumed.
     float c = 0.0f;
-    for (int base = 0; base < nit; base += PF) {
+    float2 sg = make_float2(0.f, 0.f);
+    float4 sc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int base = 0; base < len; base += PF) {
 #pragma unroll
       for (int j = 0; j < PF; ++j) {
         const int t = base + j;
-        if (t < nit) {
-          if (t < len) {
-            const float cpt = (t < sq.p_len) ? cp : 0.0f;
-            const f2 x = {fmaf(cpt, xp[j].x, fmaf(ca, xa[j].x, bias.x)), fmaf(cpt, xp[j].y, fmaf(ca, xa[j].y, bias.y))};
-            const f2 a = matvec_half(wk, wx, h0buf + ((t + 1) & 1) * HV + 28 * s, x);
-            const float v0 = fmaf(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(kact * a.x)), actA, actB);
-            const float v1 = fast_sigmoid(a.y);
-            const float gi = from_even(v0), gf = from_even(v1);      // lane 1: (i, f); its own v0, v1 = (g, o)
-            c = fmaf(gf, c, gi * v0);
-            const float tc = fast_tanh(c);
-            const float h = v1 * tc;
-            const float y = has_mask ? mk[j] * h : h;
-            float* grow = gout + (unsigned)(t * S2G_G);
-            float* crow = cout + (unsigned)(t * S2G_G);
-            if (valid) *reinterpret_cast<float2*>(grow + lo2) = make_float2(v0, v1);
-            if (owner) {
-              *reinterpret_cast<float4*>(crow + lo4) = make_float4(c, tc, h, y);
-              h0buf[(t & 1) * HV + hp] = h;
-              ybuf[(t & 1) * 64 + yp] = y;
-            }
+        if (t < len) {
+          float hv[28];
+          load_slice28(h0buf + ((t + 1) & 1) * HV + 28 * s, hv);
+          if (t >= 1) {
+            float* grow = gout + (unsigned)((t - 1) * S2G_G);
+            float* crow = cout + (unsigned)((t - 1) * S2G_G);
+            if (valid) *reinterpret_cast<float2*>(grow + lo2) = sg;
+            if (owner) *reinterpret_cast<float4*>(crow + lo4) = sc;
+            ISSUE_A((j + PF - 1) % PF, t - 1 + PF, tk)
+            tk = tok_lds[min(t + PF, len - 1)];
           }
+          const float cpt = (t < sq.p_len) ? cp : 0.0f;
+          const f2 x = {fmaf(cpt, xp[j].x, fmaf(ca, xa[j].x, bias.x)), fmaf(cpt, xp[j].y, fmaf(ca, xa[j].y, bias.y))};
+          const f2 a = matvec_half(wk, wx, hv, x);
+          const float v0 = fmaf(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(kact * a.x)), actA, actB);
+          const float v1 = fast_sigmoid(a.y);
+          const float gi = from_even(v0), gf = from_even(v1);      // lane 1: (i, f); its own v0, v1 = (g, o)
+          c = fmaf(gf, c, gi * v0);
+          const float tc = fast_tanh(c);
+          const float h = v1 * tc;
+          const float y = has_mask ? mk[j] * h : h;
+          if (owner) {
+            h0buf[(t & 1) * HV + hp] = h;
+            ybuf[(t & 1) * 64 + yp] = y;
+          }
+          sg = make_float2(v0, v1);
+          sc = make_float4(c, tc, h, y);
           __syncthreads();
         }
-        // the slot is refilled only after its last use, so it keeps its registers across iterations
-        ISSUE_A(j, t + PF, tk)
-        tk = tok_lds[min(t + PF + 1, len - 1)];
       }
     }
+    {
+      float* grow = gout + (unsigned)((len - 1) * S2G_G);
+      float* crow = cout + (unsigned)((len - 1) * S2G_G);
+      if (valid) *reinterpret_cast<float2*>(grow + lo2) = sg;
+      if (owner) *reinterpret_cast<float4*>(crow + lo4) = sc;
+    }
+    __syncthreads();      // the two pipeline-drain iterations of the other waves
+    __syncthreads();
   } else {
     float* gout = gates1 + row0;
     float* cout = cell1 + row0;
     __syncthreads();
+    __syncthreads();      // pipeline fill: layer 1 starts two steps behind layer 0
+    __syncthreads();
     float c = 0.0f;
-    for (int tau = 0; tau < nit; ++tau) {
-      const int t = tau - 2;
-      if (t >= 0) {
-        const float2 pin = *reinterpret_cast<const float2*>(p1buf + (t & 1) * 256 + lo2);
-        const f2 a = matvec_half(wk, wx, h1buf + ((t + 1) & 1) * HV + 28 * s, (f2){pin.x, pin.y});
-        const float v0 = fmaf(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(kact * a.x)), actA, actB);
-        const float v1 = fast_sigmoid(a.y);
-        const float gi = from_even(v0), gf = from_even(v1);
-        c = fmaf(gf, c, gi * v0);
-        const float tc = fast_tanh(c);
-        const float h = v1 * tc;
-        float* grow = gout + (unsigned)(t * S2G_G);
-        float* crow = cout + (unsigned)(t * S2G_G);
-        if (valid) *reinterpret_cast<float2*>(grow + lo2) = make_float2(v0, v1);
-        if (owner) {
-          *reinterpret_cast<float4*>(crow + lo4) = make_float4(c, tc, h, 0.0f);
-          h1buf[(t & 1) * HV + hp] = h;
-          if (t == len - 1) hT[(size_t)n * S2G_H + u] = h;
-        }
+    float2 sg = make_float2(0.f, 0.f);
+    float4 sc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t < len; ++t) {
+      float hv[28];
+      load_slice28(h1buf + ((t + 1) & 1) * HV + 28 * s, hv);
+      const float2 pin = *reinterpret_cast<const float2*>(p1buf + (t & 1) * 256 + lo2);
+      if (t >= 1) {
+        float* grow = gout + (unsigned)((t - 1) * S2G_G);
+        float* crow = cout + (unsigned)((t - 1) * S2G_G);
+        if (valid) *reinterpret_cast<float2*>(grow + lo2) = sg;
+        if (owner) *reinterpret_cast<float4*>(crow + lo4) = sc;
       }
+      const f2 a = matvec_half(wk, wx, hv, (f2){pin.x, pin.y});
+      const float v0 = fmaf(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(kact * a.x)), actA, actB);
+      const float v1 = fast_sigmoid(a.y);
+      const float gi = from_even(v0), gf = from_even(v1);
+      c = fmaf(gf, c, gi * v0);
+      const float tc = fast_tanh(c);
+      const float h = v1 * tc;
+      if (owner) h1buf[(t & 1) * HV + hp] = h;
+      sg = make_float2(v0, v1);
+      sc = make_float4(c, tc, h, 0.0f);
       __syncthreads();
+    }
+    {
+      float* grow = gout + (unsigned)((len - 1) * S2G_G);
+      float* crow = cout + (unsigned)((len - 1) * S2G_G);
+      if (valid) *reinterpret_cast<float2*>(grow + lo2) = sg;
+      if (owner) {
+        *reinterpret_cast<float4*>(crow + lo4) = sc;
+        hT[(size_t)n * S2G_H + u] = sc.z;
+      }
     }
   }
 }
