@@ -64,6 +64,12 @@ typedef struct S2GGemm {
   float alpha;
 } S2GGemm;
 int s2g_gemm_f32(const S2GGemm* args, int nsplit, void* stream);
+/* the tall products of the critic's input layer (x W_ih0^T, delta W_ih0, delta (W_ih0 W_ih0^T);
+ * the W_ih part of nn.LSTM and its autograd, wgan_gp.py:189,217,247-254): C[M,N] = A[M,K] B[K,N],
+ * row-major, 160 < N <= 224, any K; ldb % 4 == 0, B 16-byte aligned and readable (zeros) up to
+ * column roundup(N, 4).  A and B are each read once per 64-row block. */
+int s2g_gemm_tall(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N, int K,
+                  void* stream);
 /* nprob problems in ONE launch.  table_dev / prefix_dev are DEVICE arrays: S2GGemm[nprob] (every
  * problem of the weight-gradient shape: A = [rows, M] with sam == 1, M % 4 == 0, M <= 256,
  * sak % 4 == 0 and a 16-byte aligned base, kchunk > 0 set by the caller, no bias / act /
@@ -113,7 +119,8 @@ int s2g_lstm2_bwd2(const S2GSeq* seqs, int nseq, int rows_per_seq, const float* 
                    float* abar0, float* abar1, void* stream);
 
 /* permuted copies of lstm.weight_ih_l0 and the summed biases (Discriminator parameters,
- * wgan_gp.py:189): WT0 [V,200], W0p [200,V], b0/b1 [200]. */
+ * wgan_gp.py:189): WT0 [V,200], W0p [200, roundup(V,4)] (pad columns must
+ * be zero on entry and are left untouched), b0/b1 [200]. */
 int s2g_pack_critic(const float* wih0, const float* bih0, const float* bhh0, const float* bih1,
                     const float* bhh1, float* WT0, float* W0p, float* b0, float* b1, int V, void* stream);
 /* sequence descriptors of the fused critic batch [real B | fake B | interp B | interp B with

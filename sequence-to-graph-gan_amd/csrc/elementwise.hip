@@ -154,7 +154,7 @@ extern "C" __global__ __launch_bounds__(256) void s2g_k_adam(float* __restrict__
 }
 
 // ------------------------------------------------------------------ critic weight packing
-// WT0[v][j'] = W_ih0[pt_row(j')][v];  W0p[j'][v] = W_ih0[pt_row(j')][v];
+// WT0[v][j'] = W_ih0[pt_row(j')][v];  W0p[j'][v] = W_ih0[pt_row(j')][v] (row stride roundup(V,4));
 // b0[j'] = b_ih0 + b_hh0, b1[j'] = b_ih1 + b_hh1 (internal gate order j' = 4*unit + gate)
 extern "C" __global__ void s2g_k_pack_critic(const float* __restrict__ wih0, const float* __restrict__ bih0,
                                              const float* __restrict__ bhh0, const float* __restrict__ bih1,
@@ -165,7 +165,7 @@ extern "C" __global__ void s2g_k_pack_critic(const float* __restrict__ wih0, con
   if (i < S2G_G * V) {
     int j = i / V, v = i % V;
     float w = wih0[(long)pt_row(j) * V + v];
-    W0p[i] = w;
+    W0p[(long)j * ((V + 3) & ~3) + v] = w;      // rows padded to a multiple of 4 floats (pad stays 0)
     WT0[(long)v * S2G_G + j] = w;
   }
   if (i < S2G_G) {

@@ -345,7 +345,7 @@ __device__ __forceinline__ void wgrad_tile(const GemmArgs& g, const int bx, cons
       // pipe idle.  Past the last K-block they read element 0 and are discarded.
 #pragma unroll
       for (int kk = 0; kk < BK; kk += 2) {
-        if ((kk & 3) == 0) fetch(kk >> 2);
+        if (kk < 16) fetch(kk >> 1);          // first half of the loop: the rows land before the LDS store
         const float a0 = As[aoff + kk * WLD_A];
         const float a1 = As[aoff + 32 + kk * WLD_A];
         const float b0 = Bs[boff + kk * LDS_LD];
@@ -483,6 +483,135 @@ extern "C" __global__ __launch_bounds__(256) void s2g_k_colsum(const float* __re
   if (w == 0 && c < cols)
     part[(long)blockIdx.y * cols + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] +
                                         red[3][threadIdx.x];
+}
+
+// Tall product C[M,N] = A[M,K] B[K,N] with M = all sequence-steps and K, N <= 224 (the input
+// projection x W_ih0^T, its transpose delta W_ih0 and delta (W_ih0 W_ih0^T)): a block of four waves
+// (one per SIMD) owns 128 rows and ALL N columns, so A is read exactly once and B (<= 160 KB, L2-resident) once per
+// block.  Wave w keeps NT 32x32 accumulators for rows [32w, 32w+32); per k-pair one A fragment feeds
+// NT MFMAs.  K is streamed in chunks of 32 through two LDS stages (one barrier per chunk); the next
+// chunk's global loads are issued between the MFMAs of the current one (the wave issues in order).
+// A: row-major, k contiguous (any lda, rows may be unaligned: lanes run along k).  B: row-major with
+// ldb % 4 == 0, 16-byte aligned, readable up to column roundup(N, 4) (pad columns must hold zeros).
+#define TALL_ROWS 128
+#define TALL_ALD 33
+template <int NT>
+__global__ __launch_bounds__(256) void s2g_k_gemm_tall(const float* __restrict__ A, long lda,
+                                                       const float* __restrict__ B, long ldb,
+                                                       float* __restrict__ C, long ldc, int M, int N, int K) {
+  constexpr int BLD = NT * 32 + 4;            // B stage row length (floats)
+  constexpr int NC4 = NT * 8;                 // float4 per B stage row
+  constexpr int NB = (32 * NC4 + 255) / 256;  // B float4 loads per thread per chunk
+  constexpr int STAGE = TALL_ROWS * TALL_ALD + 32 * BLD;
+  extern __shared__ __attribute__((aligned(16))) float tall_lds[];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int m0 = blockIdx.x * TALL_ROWS;
+  const int ar = tid >> 5, ak = tid & 31;     // A loader: rows ar + 8e (e < 16), column k0 + ak
+
+  float ra[16];
+  float4 rb[NB];
+  int kf = 0;                                 // first k of the chunk being fetched
+  // Out-of-range elements read element 0 and are zeroed only when the chunk is written to LDS (bit
+  // masks): nothing touches a loaded value before then, so no wait for the loads lands inside the
+  // MFMA loop.
+  unsigned liveA = 0, liveB = 0;
+  auto fetch_a = [&](int e) {
+    const int row = m0 + ar + 8 * e, k = kf + ak;
+    const bool in = row < M && k < K;
+    ra[e] = gload(A + (in ? (long)row * lda + k : 0));
+    if (e == 0) liveA = 0;
+    liveA |= in ? (1u << e) : 0u;
+  };
+  auto fetch_b = [&](int e) {
+    const int f = tid + 256 * e;
+    const int kr = f / NC4, c4 = f - kr * NC4;
+    const bool in = f < 32 * NC4 && kf + kr < K && 4 * c4 < N;
+    rb[e] = gload4(B + (in ? (long)(kf + kr) * ldb + 4 * c4 : 0));
+    if (e == 0) liveB = 0;
+    liveB |= in ? (1u << e) : 0u;
+  };
+  auto store = [&](float* S) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) S[(ar + 8 * e) * TALL_ALD + ak] = (liveA >> e) & 1u ? ra[e] : 0.0f;
+#pragma unroll
+    for (int e = 0; e < NB; ++e) {
+      const int f = tid + 256 * e;
+      const int kr = f / NC4, c4 = f - kr * NC4;
+      const bool l = (liveB >> e) & 1u;
+      float4 v;
+      v.x = l ? rb[e].x : 0.0f; v.y = l ? rb[e].y : 0.0f; v.z = l ? rb[e].z : 0.0f; v.w = l ? rb[e].w : 0.0f;
+      if (f < 32 * NC4) *reinterpret_cast<float4*>(S + TALL_ROWS * TALL_ALD + kr * BLD + 4 * c4) = v;
+    }
+  };
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[j][i] = 0.0f;
+  const int aoff = (32 * wave + (lane & 31)) * TALL_ALD + (lane >> 5);
+  const int boff = TALL_ROWS * TALL_ALD + (lane >> 5) * BLD + (lane & 31);
+
+#pragma unroll
+  for (int e = 0; e < 16; ++e) fetch_a(e);
+#pragma unroll
+  for (int e = 0; e < NB; ++e) fetch_b(e);
+  store(tall_lds);
+  __syncthreads();
+  int cur = 0;
+  for (int k0 = 0; k0 < K; k0 += 32) {
+    const float* S = tall_lds + cur * STAGE;
+    kf = k0 + 32;                             // past the last chunk every fetch is masked
+#pragma unroll
+    for (int kk = 0; kk < 32; kk += 2) {
+      if (kk < 16) {                          // all fetches in the first half: they land before the store
+        fetch_a(kk);
+        fetch_a(kk + 1);
+        if ((kk >> 1) < NB) fetch_b(kk >> 1);
+      }
+      const float a = S[aoff + kk];
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, S[boff + kk * BLD + 32 * j], acc[j], 0, 0, 0);
+    }
+    store(tall_lds + (cur ^ 1) * STAGE);      // the other stage: nobody reads it during this chunk
+    __syncthreads();
+    cur ^= 1;
+  }
+
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = 32 * j + (lane & 31);
+    if (col < N) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < M) C[(long)row * ldc + col] = acc[j][r];
+      }
+    }
+  }
+}
+
+extern "C" int s2g_launch_gemm_tall(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M,
+                                    int N, int K, hipStream_t stream) {
+  const int nt = (N + 31) / 32;
+  const dim3 grid((M + TALL_ROWS - 1) / TALL_ROWS), block(256);
+#define S2G_TALL_CASE(NT_)                                                                                   \
+  if (nt == NT_) {                                                                                           \
+    const size_t lds = 2 * (TALL_ROWS * TALL_ALD + 32 * (NT_ * 32 + 4)) * sizeof(float);                     \
+    static bool attr_done = false;                                                                           \
+    if (!attr_done) {                                                                                        \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&s2g_k_gemm_tall<NT_>),                          \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2; \
+      attr_done = true;                                                                                      \
+    }                                                                                                        \
+    hipLaunchKernelGGL((s2g_k_gemm_tall<NT_>), grid, block, lds, stream, A, lda, B, ldb, C, ldc, M, N, K);     \
+    return hipGetLastError() == hipSuccess ? 0 : -2;                                                         \
+  }
+  S2G_TALL_CASE(6) S2G_TALL_CASE(7)
+#undef S2G_TALL_CASE
+  return -1;
 }
 
 extern "C" int s2g_launch_gemm(const GemmArgs* ga, int nsplit, hipStream_t stream) {

@@ -48,6 +48,13 @@ int s2g_gemm_f32(const GemmArgs* args, int nsplit, void* stream) {
   return s2g_launch_gemm(args, nsplit, ST(stream));
 }
 
+int s2g_gemm_tall(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N, int K,
+                  void* stream) {
+  if (!A || !B || !C || M <= 0 || K <= 0 || N <= 160 || N > 224) return -1;
+  if ((ldb & 3) || ldb < ((N + 3) & ~3) || (((uintptr_t)B) & 15) || lda < K || ldc < N) return -1;
+  return s2g_launch_gemm_tall(A, lda, B, ldb, C, ldc, M, N, K, ST(stream));
+}
+
 int s2g_gemm_grouped(const GemmArgs* table_dev, const int* prefix_dev, int nprob, int total_blocks, void* stream) {
   if (!table_dev || !prefix_dev || nprob <= 0 || nprob > 64 || total_blocks <= 0) return -1;
   return s2g_launch_gemm_grouped(table_dev, prefix_dev, nprob, total_blocks, ST(stream));

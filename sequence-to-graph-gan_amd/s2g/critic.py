@@ -54,7 +54,8 @@ class CriticEngine:
         self.params = FlatBuffer(CRITIC_SHAPES(vocab), device)
         self.grads = self.params.like()
         self.WT0 = torch.empty(vocab, G4, device=device)
-        self.W0p = torch.empty(G4, vocab, device=device)
+        self.Vp = (vocab + 3) // 4 * 4          # row stride of W0p: 16-byte rows for the tall products
+        self.W0p = torch.zeros(G4, self.Vp, device=device)
         self.b0 = torch.empty(G4, device=device)
         self.b1 = torch.empty(G4, device=device)
         self.M2 = torch.empty(G4, G4, device=device)
@@ -81,7 +82,7 @@ class CriticEngine:
              ptr(self.b1), self.V, stream_ptr())
         # M2 = W_ih0 W_ih0^T (internal gate order): maps layer-0 gate gradients straight to the projected
         # input gradient (critic_iteration)
-        ops.gemm_raw(ptr(self.W0p), self.V, 1, ptr(self.WT0), G4, 1, ptr(self.M2), G4, G4, G4, self.V)
+        ops.gemm_raw(ptr(self.W0p), self.Vp, 1, ptr(self.WT0), G4, 1, ptr(self.M2), G4, G4, G4, self.V)
 
     def device_scalar(self, value: float) -> torch.Tensor:
         """A cached 1-element device tensor holding `value` (kernel arguments read on the device)."""
@@ -138,7 +139,7 @@ class CriticEngine:
     def project(self, x: torch.Tensor, out: torch.Tensor) -> None:
         """out[rows,200] = x[rows,V] @ W_ih0^T (internal gate order, no bias)."""
         rows = x.numel() // self.V
-        ops.gemm_raw(ptr(x), self.V, 1, ptr(self.WT0), G4, 1, ptr(out), G4, rows, G4, self.V)
+        ops.gemm_tall(ptr(x), self.V, ptr(self.WT0), G4, ptr(out), G4, rows, G4, self.V)
 
     def side(self):
         """The second HIP stream of critic_iteration, confined to 3/4 of the CUs: sweeps C and D run
@@ -401,7 +402,7 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
     # 175-wide direction v = coef_b * g itself feeds one weight-gradient product only and is built
     # beside sweep C (first_order below).
     r_int = 2 * B * Tw
-    ops.gemm_raw(ptr(ws["delta0"], r_int * G4), G4, 1, ptr(eng.M2), G4, 1, ptr(ws["Pv"]), G4, B * Tw, G4, G4)
+    ops.gemm_tall(ptr(ws["delta0"], r_int * G4), G4, ptr(eng.M2), G4, ptr(ws["Pv"]), G4, B * Tw, G4, G4)
     call("s2g_gp_norm_penalty_proj", ptr(ws["delta0"], r_int * G4), ptr(ws["Pv"]), B, Tw * G4, float(lambda_gp),
          float(n_global), ptr(ws["pen"]), ptr(ws["norms"]), st)
     lam = eng.device_scalar(float(lambda_gp))
@@ -435,7 +436,7 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         first-order bias gradients."""
         s_ = stream_ptr()
         # v = coef_b * (delta0 W_ih0): the direction of the penalty's second-order term in input space
-        ops.gemm_raw(ptr(ws["delta0"], r_int * G4), G4, 1, ptr(eng.W0p), V, 1, ptr(ws["G"]), V, B * Tw, V, G4)
+        ops.gemm_tall(ptr(ws["delta0"], r_int * G4), G4, ptr(eng.W0p), eng.Vp, ptr(ws["G"]), V, B * Tw, V, G4)
         call("s2g_gp_scale", ptr(ws["G"]), ptr(ws["norms"]), ptr(lam), float(n_global), Tw * V, ptr(ws["G"]), B, s_)
         call("s2g_one_hot", ptr(tokens), ptr(lengths), T, ptr(ws["xreal"]), B * T, V, s_)
         call("s2g_gp_interp", ptr(tokens), ptr(lengths), ptr(fake), ptr(alpha), B, T, Tf, V, ptr(ws["xhat"]), s_)
@@ -529,5 +530,5 @@ def critic_forward_backward_fake(eng: CriticEngine, fake: torch.Tensor, labels: 
          class_w[1], ptr(ws["dout"]), ptr(ws["losses"]), st)
     call("s2g_head_bwd_dh", ptr(ws["dout"]), ptr(p["fc.weight"]), ptr(ws["dhT"]), B, 3, st)
     eng.sweep_bwd(ws, ptr(desc), B, Tf, mask)
-    ops.gemm_raw(ptr(ws["delta0"]), G4, 1, ptr(eng.W0p), V, 1, ptr(ws["dfake"]), V, B * Tf, V, G4)
+    ops.gemm_tall(ptr(ws["delta0"]), G4, ptr(eng.W0p), eng.Vp, ptr(ws["dfake"]), V, B * Tf, V, G4)
     return ws["losses"], ws["dfake"].view(B, Tf, V)

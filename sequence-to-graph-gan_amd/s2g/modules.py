@@ -128,7 +128,7 @@ class CriticFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[1]:
             dx = torch.empty(B, T, V, device=dout.device)
-            ops.gemm_raw(ptr(d0), G4, 1, ptr(eng.W0p), V, 1, ptr(dx), V, n, V, G4)
+            ops.gemm_tall(ptr(d0), G4, ptr(eng.W0p), eng.Vp, ptr(dx), V, n, V, G4)
         return (None, dx, None, None) + tuple(g[k] for k in ctx.names)
 
 
@@ -159,7 +159,7 @@ class GradientPenaltyFn(torch.autograd.Function):
         ws["dout"].zero_(); ws["dout"][:, 0] = 1.0
         call("s2g_head_bwd_dh", ptr(ws["dout"]), ptr(eng.params.views["fc.weight"]), ptr(ws["dhT"]), B, 3, st)
         eng.sweep_bwd(ws, ptr(desc), B, T, m52, adj_seq0=0)
-        ops.gemm_raw(ptr(ws["delta0"]), G4, 1, ptr(eng.W0p), V, 1, ptr(ws["G"]), V, B * T, V, G4)
+        ops.gemm_tall(ptr(ws["delta0"]), G4, ptr(eng.W0p), eng.Vp, ptr(ws["G"]), V, B * T, V, G4)
         call("s2g_gp_norm_penalty", ptr(ws["G"]), B, T * V, 1.0, float(B), ptr(ws["pen"]), ptr(ws["norms"]), 0, st)
         gp = torch.empty(1, device=dev)
         ops.reduce_slabs(ws["pen"], 1, B, 1, 1, gp, scale=1.0 / B)
