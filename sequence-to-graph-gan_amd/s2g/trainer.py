@@ -4,6 +4,7 @@ update, same z and labels, fresh Gumbel noise).  All arithmetic runs in libs2g k
 file only sequences launches, owns the Adam state and talks to the data-parallel communicator."""
 from __future__ import annotations
 
+import contextlib
 import math
 from typing import Dict, Optional
 
@@ -70,7 +71,34 @@ class WGANGPTrainer:
             self._fake[which] = torch.empty(B, self.L, self.V, device=self.device)
         return self._fake[which]
 
-    def critic_step(self, tokens: torch.Tensor, labels: torch.Tensor, lengths: torch.Tensor, wsum: float,
+    @contextlib.contextmanager
+    def _own_stream(self):
+        """Moves the enclosed launches onto a non-blocking stream of the trainer when the caller sits on
+        the NULL stream: the critic's CU-masked second stream is a blocking stream and would otherwise
+        synchronise implicitly with every launch there.  The caller's stream waits for the work on exit."""
+        cur = torch.cuda.current_stream()
+        if not (self.D.overlap and cur.cuda_stream == 0):
+            yield
+            return
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=self.device)
+        own = self._stream
+        own.wait_stream(cur)
+        with torch.cuda.stream(own):
+            yield
+        cur.wait_stream(own)
+
+    def critic_step(self, *args, **kwargs):
+        """One critic update (wgan_gp.py:277-318); arguments of _critic_step."""
+        with self._own_stream():
+            return self._critic_step(*args, **kwargs)
+
+    def generator_step(self, *args, **kwargs):
+        """One generator update (wgan_gp.py:330-343); arguments of _generator_step."""
+        with self._own_stream():
+            return self._generator_step(*args, **kwargs)
+
+    def _critic_step(self, tokens: torch.Tensor, labels: torch.Tensor, lengths: torch.Tensor, wsum: float,
                     z: Optional[torch.Tensor] = None, U: Optional[torch.Tensor] = None,
                     alpha: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
                     update: bool = True, next_batch=None):
@@ -144,7 +172,7 @@ class WGANGPTrainer:
         self.comm.allreduce(t)
         return t[0]
 
-    def generator_step(self, labels: Optional[torch.Tensor] = None, z: Optional[torch.Tensor] = None,
+    def _generator_step(self, labels: Optional[torch.Tensor] = None, z: Optional[torch.Tensor] = None,
                        U: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
                        wsum: Optional[float] = None, update: bool = True):
         """wgan_gp.py:330-343 with the z / labels of the preceding critic_step by default."""
@@ -183,12 +211,7 @@ class WGANGPTrainer:
         synchronise with every launch when the caller sits on the NULL stream.  While the generator
         stays fixed (between two generator updates) the next batch's fake sequences are prefetched
         beside the current batch's second-order sweeps."""
-        cur = torch.cuda.current_stream()
-        if self._stream is None:
-            self._stream = torch.cuda.Stream(device=self.device)
-        own = self._stream if (self.D.overlap and cur.cuda_stream == 0) else cur
-        own.wait_stream(cur)
-        with torch.cuda.stream(own):
+        with self._own_stream():
             n = len(batches)
             for i, (tokens, labels, lengths, wsum) in enumerate(batches):
                 nz = noises[i] if noises is not None else {}
@@ -197,8 +220,7 @@ class WGANGPTrainer:
                     nn_ = noises[i + 1] if noises is not None else {}
                     nxt = dict(labels=batches[i + 1][1], z=nn_.get("z"), U=nn_.get("U"), alpha=nn_.get("alpha"),
                                mask=nn_.get("mask"), T=batches[i + 1][0].shape[1])
-                self.critic_step(tokens, labels, lengths, wsum, nz.get("z"), nz.get("U"), nz.get("alpha"),
-                                 nz.get("mask"), next_batch=nxt)
+                self._critic_step(tokens, labels, lengths, wsum, nz.get("z"), nz.get("U"), nz.get("alpha"),
+                                  nz.get("mask"), next_batch=nxt)
                 if i % self.n_critic == 0:
-                    self.generator_step(U=nz.get("U2"), mask=nz.get("mask_g"))
-        cur.wait_stream(own)
+                    self._generator_step(U=nz.get("U2"), mask=nz.get("mask_g"))
