@@ -1,0 +1,124 @@
+"""Unit checks of single libs2g entry points against plain PyTorch fp32/fp64 references of the same
+operation (the composite paths are covered by test_gpu_step.py / test_gpu_sweeps.py)."""
+import ctypes
+
+import pytest
+import torch
+
+import common
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-3          # relative fp32 bound of the north star; the kernels land ~1e-6
+
+
+def rel(a, b):
+    return ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("M,K,N,ldb", [(32768, 175, 200, 200), (1000, 200, 200, 200), (517, 200, 175, 176),
+                                         (64, 33, 161, 164), (129, 7, 224, 224)])
+def test_gemm_tall_matches_torch(M, K, N, ldb):
+    from s2g import ops
+    from s2g.ops import ptr
+    g = common.gen(11)
+    A = torch.randn(M, K, generator=g).to(DEV)
+    B = torch.zeros(K, ldb)
+    B[:, :N] = torch.randn(K, N, generator=g)
+    B = B.to(DEV)
+    C = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm_tall(ptr(A), K, ptr(B), ldb, ptr(C), N, M, N, K)
+    torch.cuda.synchronize()
+    assert rel(C, A.double() @ B[:, :N].double()) < 1e-5
+
+
+def test_gemm_tall_rejects_bad_shapes():
+    from s2g import lib
+    L = lib.get()
+    x = torch.zeros(64, 256, device=DEV)
+    s = torch.cuda.current_stream().cuda_stream
+    assert L.s2g_gemm_tall(x.data_ptr(), 200, x.data_ptr(), 200, x.data_ptr(), 200, 64, 100, 200, s) == -1   # N <= 160
+    assert L.s2g_gemm_tall(x.data_ptr(), 200, x.data_ptr(), 175, x.data_ptr(), 175, 64, 175, 200, s) == -1   # ldb % 4
+    assert L.s2g_gemm_tall(x.data_ptr(), 200, x.data_ptr(), 256, x.data_ptr(), 256, 64, 230, 200, s) == -1   # N > 224
+
+
+def test_dropout_mask_matches_torch():
+    from s2g.lib import call
+    from s2g.ops import ptr, stream_ptr
+    rows, p = 4099, 0.3
+    u = torch.rand(rows, 52, generator=common.gen(12)).to(DEV)
+    want = (u >= p).float() / (1.0 - p)
+    want[:, 50:] = 0.0
+    call("s2g_dropout_mask", ptr(u), rows, p, stream_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(u, want)
+
+
+def test_gp_norm_penalty_proj_matches_formula():
+    """pen_b = (|g_b| - 1)^2 with |g_b|^2 = sum_t delta_t . pv_t, and pv_b scaled by
+    lambda * 2 (n_b - 1) / (n_batch n_b) in place (wgan_gp.py:255-256 and the seed of the tangent sweep)."""
+    from s2g.lib import call
+    from s2g.ops import ptr, stream_ptr
+    B, T, lam, nb = 5, 37, 10.0, 7.0
+    g = common.gen(13)
+    W = torch.randn(200, 175, generator=g) * 0.2
+    delta = (torch.randn(B * T, 200, generator=g) * 0.05).to(DEV)
+    M2 = (W @ W.T).to(DEV)
+    pv = (delta @ M2).contiguous()
+    pv0 = pv.clone()
+    pen = torch.empty(B, device=DEV)
+    norms = torch.empty(B, device=DEV)
+    call("s2g_gp_norm_penalty_proj", ptr(delta), ptr(pv), B, T * 200, lam, nb, ptr(pen), ptr(norms), stream_ptr())
+    torch.cuda.synchronize()
+    gfull = (delta.double().cpu() @ W.double()).view(B, -1)
+    n = gfull.norm(dim=1)
+    assert rel(norms.cpu(), n) < TOL
+    assert rel(pen.cpu(), (n - 1) ** 2) < TOL
+    coef = lam * 2 * (n - 1) / (nb * n)
+    assert rel(pv.cpu().view(B, -1), pv0.double().cpu().view(B, -1) * coef[:, None]) < TOL
+
+
+def test_reduce_slabs_multi_matches_single():
+    from s2g.lib import S2GReduce, call
+    from s2g.ops import ptr, stream_ptr
+    g = common.gen(14)
+    jobs = []
+    for cols, nslab in ((175, 37), (50, 128), (50, 5)):
+        slabs = torch.randn(nslab, 200 * cols, generator=g).to(DEV)
+        jobs.append((slabs, cols, nslab, torch.empty(200, cols, device=DEV), torch.empty(200, cols, device=DEV)))
+    arr = (S2GReduce * len(jobs))()
+    for k, (slabs, cols, nslab, out_m, out_s) in enumerate(jobs):
+        arr[k] = S2GReduce(ptr(slabs), 200 * cols, ptr(out_m), nslab, 200, cols)
+        call("s2g_reduce_slabs", ptr(slabs), 200 * cols, nslab, 200, cols, ptr(out_s), 1, 0, 1.0, stream_ptr())
+    call("s2g_reduce_slabs_multi", arr, len(jobs), 1, 0, 1.0, stream_ptr())
+    torch.cuda.synchronize()
+    perm = torch.tensor([(j & 3) * 50 + (j >> 2) for j in range(200)])
+    for slabs, cols, nslab, out_m, out_s in jobs:
+        assert torch.equal(out_m, out_s)
+        want = torch.empty(200, cols, dtype=torch.float64)
+        want[perm] = slabs.double().cpu().sum(0).view(200, cols)
+        assert rel(out_m.cpu(), want) < 1e-5
+
+
+def test_cu_masked_stream_runs_kernels():
+    from s2g import lib
+    from s2g.lib import call
+    from s2g.ops import ptr
+    L = lib.get()
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    words = (n_cu + 31) // 32
+    mask = (ctypes.c_uint32 * words)()
+    for i in range(n_cu * 3 // 4):
+        mask[i // 32] |= 1 << (i % 32)
+    h = ctypes.c_void_p()
+    rc = L.s2g_stream_create_cu_mask(mask, words, ctypes.byref(h))
+    if rc != 0:
+        pytest.skip(f"runtime refused the CU mask (rc {rc})")
+    u = torch.full((8, 52), 0.9, device=DEV)
+    torch.cuda.synchronize()
+    call("s2g_dropout_mask", ptr(u), 8, 0.5, h.value)
+    st = torch.cuda.ExternalStream(h.value, device=torch.device(DEV))
+    st.synchronize()
+    assert float(u[0, 0]) == 2.0 and float(u[0, 51]) == 0.0
+    assert L.s2g_stream_destroy(h) == 0
+    assert L.s2g_stream_create_cu_mask(None, words, ctypes.byref(h)) == -1
