@@ -137,6 +137,11 @@ int s2g_critic_loss(const float* out, const long long* labels, int B, float inv_
                     float w1, float* dout, float* losses, void* stream);
 int s2g_generator_loss(const float* out, const long long* labels, int B, float inv_n, float inv_wsum,
                        float w0, float w1, float* dout, float* losses, void* stream);
+/* s2g_head_fwd (3B rows) + s2g_critic_loss + s2g_head_bwd_dh (3B rows) + s2g_head_bwd_w (first 2B
+ * rows, no accumulate) of one critic iteration in a single launch; hT/out/dout/dhT as in those. */
+int s2g_critic_head(const float* hT, const float* W, const float* bias, const long long* labels, int B,
+                    float inv_n, float inv_wsum, float w0, float w1, float* out, float* dout, float* losses,
+                    float* dhT, float* dW, float* db, void* stream);
 
 /* ---- gradient penalty pieces: compute_gradient_penalty (wgan_gp.py:225-257) */
 int s2g_one_hot(const int* tokens, const int* lengths, int T, float* x, long rows, int V, void* stream);

@@ -411,6 +411,72 @@ extern "C" __global__ __launch_bounds__(1024) void s2g_k_critic_loss(const float
   }
 }
 
+// The four small kernels between sweep A and sweep B of a critic iteration in ONE single-workgroup
+// launch: head forward on [real B | fake B | interp B], the loss terms and d(out) of
+// s2g_k_critic_loss, d(hT) for all 3B rows and the fc gradients over the first 2B rows (the interp
+// third's d(out) = e0 only seeds the penalty).  Phases talk through global memory + __syncthreads
+// (one workgroup = one CU, so its own stores are visible to it after the barrier).
+extern "C" __global__ __launch_bounds__(1024) void s2g_k_critic_head(
+    const float* __restrict__ hT, const float* __restrict__ W, const float* __restrict__ bias,
+    const long long* __restrict__ labels, int B, float inv_n, float inv_wsum, float w0, float w1,
+    float* __restrict__ out, float* __restrict__ dout, float* __restrict__ losses, float* __restrict__ dhT,
+    float* __restrict__ dW, float* __restrict__ db) {
+  __shared__ float red[3][16];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int i = tid; i < 3 * B * 3; i += nt) {
+    const int n = i / 3, j = i - 3 * n;
+    float s = bias[j];
+    for (int k = 0; k < S2G_H; ++k) s = fmaf(W[j * S2G_H + k], hT[n * S2G_H + k], s);
+    out[i] = s;
+  }
+  __syncthreads();
+  float lr = 0.f, lf = 0.f, lce = 0.f;
+  if (tid < B) {
+    const int b = tid, y = (int)labels[b];
+    float l, d0, d1;
+    const float* o = out + b * 3;
+    ce_on_probs(o[1], o[2], y, w0, w1, inv_wsum, l, d0, d1);
+    dout[b * 3 + 0] = -inv_n; dout[b * 3 + 1] = 0.5f * d0; dout[b * 3 + 2] = 0.5f * d1;
+    lr = -o[0] * inv_n; lce = 0.5f * l;
+    o = out + (B + b) * 3;
+    ce_on_probs(o[1], o[2], y, w0, w1, inv_wsum, l, d0, d1);
+    dout[(B + b) * 3 + 0] = inv_n; dout[(B + b) * 3 + 1] = 0.5f * d0; dout[(B + b) * 3 + 2] = 0.5f * d1;
+    lf = o[0] * inv_n; lce += 0.5f * l;
+    dout[(2 * B + b) * 3 + 0] = 1.0f; dout[(2 * B + b) * 3 + 1] = 0.0f; dout[(2 * B + b) * 3 + 2] = 0.0f;
+  }
+  lr = row16_sum(lr); lr += __shfl_xor(lr, 16); lr += __shfl_xor(lr, 32);
+  lf = row16_sum(lf); lf += __shfl_xor(lf, 16); lf += __shfl_xor(lf, 32);
+  lce = row16_sum(lce); lce += __shfl_xor(lce, 16); lce += __shfl_xor(lce, 32);
+  if ((tid & 63) == 0) { red[0][tid >> 6] = lr; red[1][tid >> 6] = lf; red[2][tid >> 6] = lce; }
+  __syncthreads();
+  if (tid < 3) {
+    float s = 0.0f;
+    for (int w = 0; w < (nt >> 6); ++w) s += red[tid][w];
+    losses[tid] = s;
+  }
+  for (int i = tid; i < 3 * B * S2G_H; i += nt) {
+    const int n = i / S2G_H, k = i - n * S2G_H;
+    dhT[i] = fmaf(dout[n * 3 + 2], W[2 * S2G_H + k], fmaf(dout[n * 3 + 1], W[S2G_H + k], dout[n * 3] * W[k]));
+  }
+  // fc gradients over the 2B real + fake rows: 4 threads per (j, k), quad-summed
+  const int q = tid & 3, o4 = tid >> 2;
+  if (o4 < 3 * S2G_H) {
+    const int j = o4 / S2G_H, k = o4 - j * S2G_H;
+    float s = 0.0f, sb = 0.0f;
+    for (int n = q; n < 2 * B; n += 4) {
+      const float d = dout[n * 3 + j];
+      s = fmaf(d, hT[n * S2G_H + k], s);
+      sb += d;
+    }
+    s = quad_sum(s);
+    sb = quad_sum(sb);
+    if (q == 0) {
+      dW[o4] = s;
+      if (k == 0) db[j] = sb;
+    }
+  }
+}
+
 // Generator loss (wgan_gp.py:333-340): g_loss = -mean(validity) + 0.5 * (0.5 * CE).
 // out: [B,3];  dout = (-inv_n, 0.25 dCE);  losses[0] = -sum validity*inv_n, losses[1] = 0.25*CE.
 extern "C" __global__ __launch_bounds__(1024) void s2g_k_generator_loss(const float* __restrict__ out,

@@ -188,6 +188,15 @@ int s2g_critic_loss(const float* out, const long long* labels, int B, float inv_
                      inv_wsum, w0, w1, dout, losses);
   return LAUNCH_OK();
 }
+int s2g_critic_head(const float* hT, const float* W, const float* bias, const long long* labels, int B, float inv_n,
+                    float inv_wsum, float w0, float w1, float* out, float* dout, float* losses, float* dhT,
+                    float* dW, float* db, void* stream) {
+  if (!hT || !W || !bias || !labels || !out || !dout || !losses || !dhT || !dW || !db || B <= 0 || B > 1024)
+    return -1;
+  hipLaunchKernelGGL(s2g_k_critic_head, dim3(1), dim3(1024), 0, ST(stream), hT, W, bias, labels, B, inv_n, inv_wsum,
+                     w0, w1, out, dout, losses, dhT, dW, db);
+  return LAUNCH_OK();
+}
 int s2g_generator_loss(const float* out, const long long* labels, int B, float inv_n, float inv_wsum, float w0,
                        float w1, float* dout, float* losses, void* stream) {
   if (!out || !labels || !dout || !losses || B <= 0 || B > 1024) return -1;

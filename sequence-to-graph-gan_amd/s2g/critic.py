@@ -388,12 +388,18 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
     # sweep A on 3B sequences
     eng.project(fake, ws["Pf"])
     eng.timed("s2g_k_lstm2_fwd", lambda: eng.sweep_fwd(ws, dptr, 3 * B, Tw, tokens, ws["Pf"], mask))
-    eng.head_fwd(ws, 3 * B)
     inv_n = 1.0 / float(n_global)
-    call("s2g_critic_loss", ptr(ws["out"]), ptr(labels), B, inv_n, inv_wsum, class_w[0], class_w[1],
-         ptr(ws["dout"]), ptr(ws["losses"]), st)
-    call("s2g_head_bwd_dh", ptr(ws["dout"]), ptr(p["fc.weight"]), ptr(ws["dhT"]), 3 * B, 3, st)
-    call("s2g_head_bwd_w", ptr(ws["dout"]), ptr(ws["hT"]), ptr(g["fc.weight"]), ptr(g["fc.bias"]), 2 * B, 3, 0, st)
+    if B <= 1024:
+        # head, loss, d(out), d(hT) and the fc gradients in one single-workgroup launch
+        call("s2g_critic_head", ptr(ws["hT"]), ptr(p["fc.weight"]), ptr(p["fc.bias"]), ptr(labels), B, inv_n,
+             inv_wsum, class_w[0], class_w[1], ptr(ws["out"]), ptr(ws["dout"]), ptr(ws["losses"]), ptr(ws["dhT"]),
+             ptr(g["fc.weight"]), ptr(g["fc.bias"]), st)
+    else:
+        eng.head_fwd(ws, 3 * B)
+        call("s2g_critic_loss", ptr(ws["out"]), ptr(labels), B, inv_n, inv_wsum, class_w[0], class_w[1],
+             ptr(ws["dout"]), ptr(ws["losses"]), st)
+        call("s2g_head_bwd_dh", ptr(ws["dout"]), ptr(p["fc.weight"]), ptr(ws["dhT"]), 3 * B, 3, st)
+        call("s2g_head_bwd_w", ptr(ws["dout"]), ptr(ws["hT"]), ptr(g["fc.weight"]), ptr(g["fc.bias"]), 2 * B, 3, 0, st)
     # sweep B on 3B sequences (the interp third with d(out) = e0 and stored adjoints)
     eng.timed("s2g_k_lstm2_bwd", lambda: eng.sweep_bwd(ws, dptr, 3 * B, Tw, mask, adj_seq0=2 * B))
     # Penalty of the interp third (wgan_gp.py:247-256).  With g_t = W_ih0^T delta0_t the norm is

@@ -55,6 +55,7 @@ SIGNATURES = {
     "s2g_head_bwd_w": [P, P, P, P, I, I, I, P],
     "s2g_critic_loss": [P, P, I, F, F, F, F, P, P, P],
     "s2g_generator_loss": [P, P, I, F, F, F, F, P, P, P],
+    "s2g_critic_head": [P, P, P, P, I, F, F, F, F, P, P, P, P, P, P, P],
     "s2g_one_hot": [P, P, I, P, L, I, P],
     "s2g_gp_interp": [P, P, P, P, I, I, I, I, P, P],
     "s2g_gp_interp_dense": [P, P, P, P, I, I, I, I, P, P],
