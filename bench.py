@@ -149,8 +149,8 @@ def main():
             "s2g_k_gemm_grouped": 2.0 * 200 * (V * (3 * real + fake_steps) + 3 * 50 * (3 * real + fake_steps)),
         }
         # "name#phase" entries are the launches of one kernel inside one critic iteration (the grouped
-        # GEMM runs as two launches): their average durations add up to the per-iteration time the
-        # algorithmic work is divided by
+        # GEMM runs as three launches, one per phase): their average durations add up to the kernel's
+        # time per critic iteration
         per_iter, counts, totals, launches = {}, {}, {}, {}
         for tag, pairs in ev.items():
             name = tag.split("#")[0]
@@ -160,9 +160,16 @@ def main():
             counts[name] = counts.get(name, 0) + len(durs)
             totals[name] = totals.get(name, 0.0) + sum(durs)
         kernels = {}
-        for name, avg in per_iter.items():
-            tf = work[name] / (avg * 1e-3) / 1e12 if avg > 0 else 0.0
+        for name, per_it in per_iter.items():
+            # a kernel launched n times per critic iteration: work per launch = work per iteration / n and
+            # average launch duration = (sum of all its launches) / (number of launches); the quotient
+            # equals work per iteration / time per iteration
+            n_tags = sum(1 for tag in ev if tag.split("#")[0] == name)
+            avg = totals[name] / max(counts[name], 1)
+            tf = (work[name] / n_tags) / (avg * 1e-3) / 1e12 if avg > 0 else 0.0
             kernels[name] = {"avg_launch_ms": avg, "launches_timed": counts[name],
+                             "launches_per_critic_iteration": n_tags, "ms_per_critic_iteration": per_it,
+                             "flop_per_launch": work[name] / n_tags,
                              "ms_per_step": totals[name] / a.steps, "achieved_tflops": tf,
                              "frac": tf / FP32_PEAK_TFLOPS}
         dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
@@ -173,10 +180,7 @@ def main():
             with open(pmc) as f:
                 t = json.load(f).get(dom)
             if t:
-                # avg_launch_ms of a kernel launched several times per iteration is the sum over those
-                # launches, so the traffic is scaled the same way
-                n_tags = sum(1 for tag in ev if tag.split("#")[0] == dom)
-                traffic, traffic_src = t["bytes_per_launch"] * n_tags, t["source"]
+                traffic, traffic_src = t["bytes_per_launch"], t["source"]
         line = {
             "metric": "WGAN-GP train sequences/sec at V=175 L=512", "value": seqs / dt, "unit": "sequences/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,

@@ -66,6 +66,9 @@ class CriticEngine:
         self._wgrad_slabs = None      # split-K slabs of the weight-gradient products
         self.overlap = True           # run the work that does not depend on sweeps C/D beside them (critic_iteration)
         self._side = None             # (stream, fork event, join event, scratch) of that second stream
+        self.stream_g = None          # CU-masked stream of the prefetch hook (created with _side)
+        self._m2_events = None        # (weights packed, M2 built) when M2 is built on a side stream
+        self._m2_pending = False
         self._ws_key = None
         self.ws: Dict[str, torch.Tensor] = {}
 
@@ -81,8 +84,28 @@ class CriticEngine:
              ptr(p["lstm.bias_ih_l1"]), ptr(p["lstm.bias_hh_l1"]), ptr(self.WT0), ptr(self.W0p), ptr(self.b0),
              ptr(self.b1), self.V, stream_ptr())
         # M2 = W_ih0 W_ih0^T (internal gate order): maps layer-0 gate gradients straight to the projected
-        # input gradient (critic_iteration)
-        ops.gemm_raw(ptr(self.W0p), self.Vp, 1, ptr(self.WT0), G4, 1, ptr(self.M2), G4, G4, G4, self.V)
+        # input gradient (critic_iteration).  Its first reader comes after sweeps A and B of the next
+        # iteration, so with the side streams up it is built there, off the caller's stream.
+        side = self._side if self.overlap else None
+        if side:
+            if self._m2_events is None:
+                self._m2_events = (torch.cuda.Event(), torch.cuda.Event())
+            packed, ready = self._m2_events
+            packed.record()
+            with torch.cuda.stream(side[1]):
+                side[1].wait_event(packed)
+                ops.gemm_raw(ptr(self.W0p), self.Vp, 1, ptr(self.WT0), G4, 1, ptr(self.M2), G4, G4, G4, self.V)
+                ready.record()
+            self._m2_pending = True
+        else:
+            ops.gemm_raw(ptr(self.W0p), self.Vp, 1, ptr(self.WT0), G4, 1, ptr(self.M2), G4, G4, G4, self.V)
+
+    def m2(self) -> torch.Tensor:
+        """M2 for a reader on the current stream (ordered behind a build that runs on the side stream)."""
+        if self._m2_pending:
+            torch.cuda.current_stream().wait_event(self._m2_events[1])
+            self._m2_pending = False
+        return self.M2
 
     def device_scalar(self, value: float) -> torch.Tensor:
         """A cached 1-element device tensor holding `value` (kernel arguments read on the device)."""
@@ -163,13 +186,24 @@ class CriticEngine:
                 self._side = False
                 return None
             stream = torch.cuda.ExternalStream(handle.value, device=self.device)
+            handles = [handle.value]
+            # a second stream under the same mask for the caller's prefetch hook, so that it runs beside
+            # (not behind) this iteration's own work on the first one
+            handle_g = ctypes.c_void_p()
+            try:
+                call("s2g_stream_create_cu_mask", mask, words, ctypes.byref(handle_g))
+                self.stream_g = torch.cuda.ExternalStream(handle_g.value, device=self.device)
+                handles.append(handle_g.value)
+            except S2GError:
+                self.stream_g = None
             import atexit
 
-            def close(h=handle.value, dev=self.device):
-                # destroy the stream while the HIP runtime is still up (leaving it to process teardown
+            def close(hs=tuple(handles), dev=self.device):
+                # destroy the streams while the HIP runtime is still up (leaving it to process teardown
                 # crashes in a runtime finalizer)
                 torch.cuda.synchronize(dev)
-                call("s2g_stream_destroy", h)
+                for h in hs:
+                    call("s2g_stream_destroy", h)
             atexit.register(close)
             # The masked stream is a blocking stream (the call takes no flags): it synchronises
             # implicitly with the NULL stream, torch's default.  The sweeps it must run beside are
@@ -408,7 +442,7 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
     # 175-wide direction v = coef_b * g itself feeds one weight-gradient product only and is built
     # beside sweep C (first_order below).
     r_int = 2 * B * Tw
-    ops.gemm_tall(ptr(ws["delta0"], r_int * G4), G4, ptr(eng.M2), G4, ptr(ws["Pv"]), G4, B * Tw, G4, G4)
+    ops.gemm_tall(ptr(ws["delta0"], r_int * G4), G4, ptr(eng.m2()), G4, ptr(ws["Pv"]), G4, B * Tw, G4, G4)
     call("s2g_gp_norm_penalty_proj", ptr(ws["delta0"], r_int * G4), ptr(ws["Pv"]), B, Tw * G4, float(lambda_gp),
          float(n_global), ptr(ws["pen"]), ptr(ws["norms"]), st)
     lam = eng.device_scalar(float(lambda_gp))
@@ -478,11 +512,16 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
             stream_c.wait_event(fork)
             eng.timed("s2g_k_lstm2_tangent", lambda: eng.sweep_tangent(ws, drel, B, mrel, r_int))
             after_c.record()
+        if prefetch is not None and eng.stream_g is not None:
+            # the hook's work (not part of the join) starts with the fork, on a masked stream of its own
+            with torch.cuda.stream(eng.stream_g):
+                eng.stream_g.wait_event(fork)
+                prefetch()
         with torch.cuda.stream(stream2):
             stream2.wait_event(after_c)
             _wgrad_launch(eng, built, 1)
             join.record()
-            if prefetch is not None:
+            if prefetch is not None and eng.stream_g is None:
                 prefetch()          # not part of the join: it may run on beside this iteration's tail
         with torch.cuda.stream(stream_c):
             after_d = torch.cuda.Event()

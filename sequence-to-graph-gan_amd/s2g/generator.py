@@ -50,6 +50,7 @@ class GeneratorEngine:
         self.num_batches_tracked = 0
         self.scratch = ops.Scratch(device)
         self.saved: Dict[str, torch.Tensor] = {}
+        self.last_layer_ready: Optional[torch.cuda.Event] = None   # set while that layer's update is in flight
 
     def load(self, state: Dict[str, torch.Tensor]) -> None:
         for k, v in self.params.views.items():
@@ -99,6 +100,9 @@ class GeneratorEngine:
         if training:
             self.num_batches_tracked += 1
         logits = torch.empty(B, self.L * self.V, device=dev)
+        if self.last_layer_ready is not None:
+            # the output Linear's update may still be running on another stream (trainer._generator_step)
+            torch.cuda.current_stream().wait_event(self.last_layer_ready)
         ops.linear_fwd(a3, p["model.8.weight"], p["model.8.bias"], logits)
         mode = ops.MODES.get(act, 2)
         if mode == 0 and U is None:
@@ -126,9 +130,26 @@ class GeneratorEngine:
              ptr(self.params.views[name + ".weight"]), ptr(inv), ptr(dpre), B, F_, stream_ptr())
         return dpre
 
-    def backward(self, dy: torch.Tensor) -> None:
+    def last_layer_grads(self, dl2: torch.Tensor, a3: torch.Tensor, scratch: ops.Scratch) -> None:
+        """Gradients of the output Linear (99.6 % of the generator's parameters) on the current stream."""
+        g = self.grads.views
+        ops.linear_bwd_dw(dl2, a3, g["model.8.weight"], scratch)
+        ops.colsum(dl2, dl2.shape[0], self.L * self.V, self.L * self.V, g["model.8.bias"], scratch)
+
+    def last_layer_range(self):
+        """[lo, hi) of the output Linear's weight and bias in the flat parameter buffer (adjacent views)."""
+        lo = self.params.offsets["model.8.weight"][0]
+        ob, nb, _ = self.params.offsets["model.8.bias"]
+        return lo, ob + (nb + 3) // 4 * 4
+
+    def backward(self, dy: torch.Tensor, last_layer=None) -> None:
         """Fills self.grads from d loss/d y with this rank's share: summing the buffer over ranks
-        gives the global gradient (BN gamma/beta enter as global/world)."""
+        gives the global gradient (BN gamma/beta enter as global/world).
+
+        last_layer: optional callable(dl2, a3) that takes over the output Linear's gradients (the
+        trainer runs them, and that layer's update, on a second stream beside the rest of this
+        backward: a chain of small launch-bound kernels); it must keep dl2 alive until its work is
+        ordered before the caller's stream again."""
         s = self.saved
         if not s:
             raise S2GError("generator.backward called without a saved forward")
@@ -136,10 +157,12 @@ class GeneratorEngine:
         p, g, sc, dev = self.params.views, self.grads.views, self.scratch, self.device
         dlogits = ops.gumbel_softmax_bwd(s["y_soft"], dy.contiguous().view_as(s["y_soft"]), s["scale"])
         dl2 = dlogits.view(B, self.L * self.V)
-        ops.linear_bwd_dw(dl2, s["a3"], g["model.8.weight"], sc)
-        ops.colsum(dl2, B, self.L * self.V, self.L * self.V, g["model.8.bias"], sc)
         da3 = torch.empty(B, 512, device=dev)
         ops.linear_bwd_dx(dl2, p["model.8.weight"], da3, sc)
+        if last_layer is None:
+            self.last_layer_grads(dl2, s["a3"], sc)
+        else:
+            last_layer(dl2, s["a3"])
         dpre3 = self._bn_bwd(s["a3"], da3, s["xhat3"], s["inv3"], "model.6", B, 512)
         ops.linear_bwd_dw(dpre3, s["a2"], g["model.5.weight"], sc)
         ops.colsum(dpre3, B, 512, 512, g["model.5.bias"], sc)

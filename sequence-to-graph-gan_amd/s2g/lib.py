@@ -12,7 +12,8 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libs2g.so")
+# S2G_LIB points kernel-tuning tools at an alternative build of the same library
+LIB_PATH = os.environ.get("S2G_LIB") or os.path.join(_HERE, "libs2g.so")
 
 P, I, L, F = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 

@@ -17,7 +17,9 @@ MASKW = 52
 
 
 def stream_ptr() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    """Raw handle of torch's current HIP stream (the C-level getter: torch.cuda.current_stream() costs
+    several microseconds of Python per call, and every launch asks for it)."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def _chk(t: torch.Tensor, dtype=torch.float32, name="tensor"):

@@ -58,12 +58,19 @@ class WGANGPTrainer:
         self._fake_cur = 0
         self._prefetched = None       # dict(z, labels, done event) of the fake batch the last critic_step prepared
         self._stream = None           # non-blocking stream full_step runs on (see full_step)
+        self._g_pending = None        # (done event, tensors kept alive) of a generator update on the side stream
+        self._g_scratch = ops.Scratch(self.device)
         self.last: Dict[str, torch.Tensor] = {}
 
     # ------------------------------------------------------------------ updates
-    def _adam(self, eng, m, v, step):
-        self.comm.allreduce(eng.grads.flat)
-        ops.adam(eng.params.flat, eng.grads.flat, m, v, self.lr, self.b1, self.b2, self.eps, step)
+    def _adam(self, eng, m, v, step, lo: int = 0, hi: Optional[int] = None):
+        """Gradient all-reduce + Adam on [lo, hi) of the engine's flat buffers (everything by default)."""
+        hi = eng.params.total if hi is None else hi
+        if hi <= lo:
+            return
+        g = eng.grads.flat[lo:hi]
+        self.comm.allreduce(g)
+        ops.adam(eng.params.flat[lo:hi], g, m[lo:hi], v[lo:hi], self.lr, self.b1, self.b2, self.eps, step)
 
     def _fake_buf(self, which: int, B: int) -> torch.Tensor:
         # persistent output buffers: stable pointers let the grouped-GEMM problem table be reused
@@ -114,6 +121,7 @@ class WGANGPTrainer:
         pre = self._prefetched
         self._prefetched = None
         if pre is not None and pre["labels"] is labels and (z is None or z is pre["z"]):
+            self._join_generator()
             z, fake = pre["z"], self._fake_buf(self._fake_cur, B)
             torch.cuda.current_stream().wait_event(pre["done"])
             if alpha is None:
@@ -127,6 +135,7 @@ class WGANGPTrainer:
                 z = torch.randn(B, LATENT, device=dev)
             fake = self.G.forward(z, labels, U, self.tau, self.hard, training=True, save=False,
                                   out=self._fake_buf(self._fake_cur, B))    # .detach(): no graph is kept
+            self._join_generator(waited=True)     # the forward waited for a pending output-layer update
         if alpha is None:
             alpha = torch.rand(B, device=dev)
         Tw = max(T, self.L)
@@ -134,12 +143,12 @@ class WGANGPTrainer:
             mask = dropout_mask(3 * B * Tw, self.drop_rate, dev)
         prefetch = None
         if next_batch is not None and self.D.overlap and self.comm.world == 1:
-            nz = next_batch.get("z")
-            nxt = dict(labels=next_batch["labels"], z=nz if nz is not None else torch.randn(B, LATENT, device=dev),
-                       done=torch.cuda.Event())
+            nxt = dict(labels=next_batch["labels"], z=next_batch.get("z"), done=torch.cuda.Event())
             other = self._fake_buf(self._fake_cur ^ 1, B)
 
             def prefetch():
+                if nxt["z"] is None:        # drawn on the prefetch stream: nothing of it sits on the caller's
+                    nxt["z"] = torch.randn(B, LATENT, device=dev)
                 self.G.forward(nxt["z"], nxt["labels"], next_batch.get("U"), self.tau, self.hard, training=True,
                                save=False, out=other)
                 nxt["done"].record()
@@ -174,8 +183,10 @@ class WGANGPTrainer:
 
     def _generator_step(self, labels: Optional[torch.Tensor] = None, z: Optional[torch.Tensor] = None,
                        U: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
-                       wsum: Optional[float] = None, update: bool = True):
-        """wgan_gp.py:330-343 with the z / labels of the preceding critic_step by default."""
+                       wsum: Optional[float] = None, update: bool = True, defer_join: bool = False):
+        """wgan_gp.py:330-343 with the z / labels of the preceding critic_step by default.
+        defer_join: return while the output Linear's update may still run on the side stream; the next
+        generator forward waits for it just before that layer (full_step uses this)."""
         labels = self.last["labels"] if labels is None else labels
         z = self.last["z"] if z is None else z
         wsum = self.last["wsum"] if wsum is None else wsum
@@ -188,12 +199,51 @@ class WGANGPTrainer:
         if mask is None and self.drop_rate > 0.0:
             mask = dropout_mask(B * self.L, self.drop_rate, self.device)
         losses, dfake = critic_forward_backward_fake(self.D, fake, labels, n_global, 1.0 / wsum, mask, CLASS_W)
-        self.G.backward(dfake)
-        if update:
+        side = self.D.side() if (update and self.D.overlap) else None
+        if side is None:
+            self.G.backward(dfake)
+            if update:
+                self.tG += 1
+                self._adam(self.G, self.mG, self.vG, self.tG)
+        else:
+            # The output Linear holds 99.6 % of the parameters: its weight gradient and Adam update are
+            # HBM-bound and independent of the rest of the backward (a chain of small kernels), so they
+            # run beside it on the critic's CU-masked stream (idle now), which leaves a quarter of the
+            # CUs to the chain: the grid-stride Adam would otherwise hold every wave slot of the chip.
+            self._join_generator()
             self.tG += 1
-            self._adam(self.G, self.mG, self.vG, self.tG)
+            stream_s = side[0]
+            lo, hi = self.G.last_layer_range()
+            done, keep = torch.cuda.Event(), []
+
+            def last_layer(dl2, a3):
+                ready = torch.cuda.Event()
+                ready.record()
+                keep.extend((dl2, a3))        # allocated on this stream, read on the other: alive until the join
+                with torch.cuda.stream(stream_s):
+                    stream_s.wait_event(ready)
+                    self.G.last_layer_grads(dl2, a3, self._g_scratch)
+                    self._adam(self.G, self.mG, self.vG, self.tG, lo, hi)
+                    done.record()
+
+            self.G.backward(dfake, last_layer=last_layer)
+            self._adam(self.G, self.mG, self.vG, self.tG, 0, lo)
+            self._adam(self.G, self.mG, self.vG, self.tG, hi, self.G.params.total)
+            self.G.last_layer_ready = done
+            self._g_pending = (done, keep)
+            if not defer_join:
+                self._join_generator()
         self.last["g_parts"] = losses
         return losses
+
+    def _join_generator(self, waited: bool = False) -> None:
+        """Orders the current stream behind a generator update still running on the side stream
+        (waited: the stream already waited for it, only the bookkeeping is left)."""
+        if self._g_pending is not None:
+            if not waited:
+                torch.cuda.current_stream().wait_event(self._g_pending[0])
+            self._g_pending = None
+            self.G.last_layer_ready = None
 
     def g_loss(self) -> torch.Tensor:
         l = self.last["g_parts"]
@@ -223,4 +273,5 @@ class WGANGPTrainer:
                 self._critic_step(tokens, labels, lengths, wsum, nz.get("z"), nz.get("U"), nz.get("alpha"),
                                   nz.get("mask"), next_batch=nxt)
                 if i % self.n_critic == 0:
-                    self._generator_step(U=nz.get("U2"), mask=nz.get("mask_g"))
+                    self._generator_step(U=nz.get("U2"), mask=nz.get("mask_g"), defer_join=i + 1 < n)
+            self._join_generator()

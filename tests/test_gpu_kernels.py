@@ -100,6 +100,38 @@ def test_reduce_slabs_multi_matches_single():
         assert rel(out_m.cpu(), want) < 1e-5
 
 
+@pytest.mark.parametrize("B", [1, 5, 64, 257])
+def test_critic_head_matches_separate_kernels(B):
+    """The one-launch head agrees with head forward + critic loss + head backward launched one by one
+    (fc(h_T), wgan_gp.py:221; loss terms, wgan_gp.py:299-313)."""
+    from s2g.lib import call
+    from s2g.ops import ptr, stream_ptr
+    g = common.gen(15 + B)
+    hT = torch.randn(3 * B, 50, generator=g).to(DEV)
+    W = (torch.randn(3, 50, generator=g) * 0.3).to(DEV)
+    bias = torch.randn(3, generator=g).to(DEV)
+    labels = torch.randint(0, 2, (B,), generator=g).to(DEV)
+    inv_n, inv_wsum, w0, w1 = 1.0 / B, 1.0 / float((1.0 + labels.float()).sum()), 1.0, 2.0
+    st = stream_ptr()
+
+    def bufs():
+        return [torch.full(s, float("nan"), device=DEV) for s in ((3 * B, 3), (3 * B, 3), (3,), (3 * B, 50), (3, 50), (3,))]
+
+    out, dout, losses, dhT, dW, db = bufs()
+    call("s2g_head_fwd", ptr(hT), ptr(W), ptr(bias), ptr(out), 3 * B, 3, st)
+    call("s2g_critic_loss", ptr(out), ptr(labels), B, inv_n, inv_wsum, w0, w1, ptr(dout), ptr(losses), st)
+    call("s2g_head_bwd_dh", ptr(dout), ptr(W), ptr(dhT), 3 * B, 3, st)
+    call("s2g_head_bwd_w", ptr(dout), ptr(hT), ptr(dW), ptr(db), 2 * B, 3, 0, st)
+    out2, dout2, losses2, dhT2, dW2, db2 = bufs()
+    call("s2g_critic_head", ptr(hT), ptr(W), ptr(bias), ptr(labels), B, inv_n, inv_wsum, w0, w1, ptr(out2),
+         ptr(dout2), ptr(losses2), ptr(dhT2), ptr(dW2), ptr(db2), st)
+    torch.cuda.synchronize()
+    assert rel(out2, hT.double() @ W.double().T + bias.double()) < 1e-5
+    for a, b in ((out2, out), (dout2, dout), (losses2, losses), (dhT2, dhT), (dW2, dW), (db2, db)):
+        assert torch.isfinite(a).all()
+        assert rel(a, b) < 1e-5
+
+
 def test_cu_masked_stream_runs_kernels():
     from s2g import lib
     from s2g.lib import call
