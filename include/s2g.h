@@ -179,6 +179,15 @@ int s2g_bn_lrelu_bwd_stats(const float* y, float* dy, const float* xhat, float* 
                            void* stream);
 int s2g_bn_bwd_apply(const float* dyh, const float* xhat, const float* sums, float n_global,
                      const float* gamma, const float* invstd, float* dx, int B, int F, void* stream);
+/* single-process forms (batch statistics of nn.BatchNorm1d in train mode need no all-reduce then,
+ * wgan_gp.py:150,156-157): s2g_bn_stats + s2g_bn_lrelu_apply, and s2g_bn_lrelu_bwd_stats +
+ * s2g_bn_bwd_apply with dgamma / dbeta written directly, each in one launch */
+int s2g_bn_lrelu_fwd_fused(const float* x, const float* gamma, const float* beta, float* run_mean,
+                           float* run_var, float eps, float momentum, int update_running, float* y,
+                           float* xhat, float* invstd, int B, int F, void* stream);
+int s2g_bn_lrelu_bwd_fused(const float* y, const float* dy, const float* xhat, const float* gamma,
+                           const float* invstd, float* dgamma, float* dbeta, float* dx, int B, int F,
+                           void* stream);
 
 /* ---- optimiser: torch.optim.Adam(lr, betas) as built at wgan_gp.py:405-406; `step` counts from 1;
  * the gradient is multiplied by gscale first (1/world_size after a SUM all-reduce). */

@@ -14,17 +14,23 @@ extern "C" __global__ void s2g_k_embed_mul(const float* __restrict__ z, const lo
   int b = i / D, k = i % D;
   out[i] = z[i] * emb[labels[b] * D + k];
 }
-// demb[c][k] = sum_{b: labels[b]==c} z[b][k] * dout[b][k]   (one thread per (c,k); B is small)
+// demb[c][k] = sum_{b: labels[b]==c} z[b][k] * dout[b][k]   (16 lanes = one DPP row per (c,k), each
+// lane taking every 16th sample; blockDim.x must be a multiple of 16)
 extern "C" __global__ void s2g_k_embed_mul_bwd(const float* __restrict__ z, const long long* __restrict__ labels,
                                                const float* __restrict__ dout, float* __restrict__ demb, int B,
                                                int D, int n_classes) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_classes * D) return;
-  int c = i / D, k = i % D;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = t >> 4, r = t & 15;
+  const bool live = i < n_classes * D;
+  const int ic = live ? i : 0;
+  const int c = ic / D, k = ic % D;
   float s = 0.0f;
-  for (int b = 0; b < B; ++b)
-    if (labels[b] == c) s += z[b * D + k] * dout[b * D + k];
-  demb[i] = s;
+  for (int b = r; b < B; b += 16) {
+    const float p = z[b * D + k] * dout[b * D + k];
+    s += (labels[b] == c) ? p : 0.0f;
+  }
+  s = row16_sum(s);
+  if (live && r == 0) demb[i] = s;
 }
 
 // y = x > 0 ? x : 0.2 x  applied in place is fused into the GEMM epilogue; its backward:
@@ -118,6 +124,83 @@ extern "C" __global__ void s2g_k_bn_bwd_apply(const float* __restrict__ dyh, con
   for (int b = 0; b < B; ++b) {
     long i = (long)b * F + f;
     dx[i] = gi * (dyh[i] - a - xhat[i] * c);
+  }
+}
+
+// Single-process forms of the two BatchNorm halves (no all-reduce in between): one launch per layer.
+// Block = 32 features x 8 row lanes; a thread sums rows rl, rl+8, ... of its feature, the 8 partials
+// meet in LDS and every thread adds them in the same fixed order (deterministic), then normalises
+// the rows it summed.  Same outputs as s2g_k_bn_stats + s2g_k_bn_lrelu_apply (training mode).
+#define BN_FX 32
+#define BN_RL 8
+extern "C" __global__ __launch_bounds__(BN_FX * BN_RL) void s2g_k_bn_lrelu_fwd_fused(
+    const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* __restrict__ run_mean, float* __restrict__ run_var, float eps, float momentum, int update_running,
+    float* __restrict__ y, float* __restrict__ xhat, float* __restrict__ invstd_out, int B, int F) {
+  __shared__ float red[2][BN_RL][BN_FX];
+  const int fx = threadIdx.x % BN_FX, rl = threadIdx.x / BN_FX;
+  const int f = blockIdx.x * BN_FX + fx;
+  const bool live = f < F;
+  const int fc = live ? f : F - 1;
+  float s = 0.0f, q = 0.0f;
+  for (int b = rl; b < B; b += BN_RL) { const float v = x[(long)b * F + fc]; s += v; q = fmaf(v, v, q); }
+  red[0][rl][fx] = s; red[1][rl][fx] = q;
+  __syncthreads();
+  s = 0.0f; q = 0.0f;
+#pragma unroll
+  for (int r = 0; r < BN_RL; ++r) { s += red[0][r][fx]; q += red[1][r][fx]; }
+  const float n = (float)B;
+  const float mean = s / n;
+  const float var = fmaxf(q / n - mean * mean, 0.0f);
+  const float inv = 1.0f / sqrtf(var + eps);
+  if (live && rl == 0) {
+    if (update_running) {
+      const float unb = n > 1.0f ? var * n / (n - 1.0f) : var;
+      run_mean[f] = (1.0f - momentum) * run_mean[f] + momentum * mean;
+      run_var[f] = (1.0f - momentum) * run_var[f] + momentum * unb;
+    }
+    invstd_out[f] = inv;
+  }
+  if (!live) return;
+  const float ga = gamma[f], be = beta[f];
+  for (int b = rl; b < B; b += BN_RL) {
+    const long i = (long)b * F + f;
+    const float xh = (x[i] - mean) * inv;
+    xhat[i] = xh;
+    const float v = fmaf(xh, ga, be);
+    y[i] = v > 0.0f ? v : 0.2f * v;
+  }
+}
+// backward in one launch: dyh = dy * lrelu'(y); dbeta = sum dyh; dgamma = sum dyh * xhat;
+// dx = gamma * invstd * (dyh - dbeta/B - xhat * dgamma/B)
+extern "C" __global__ __launch_bounds__(BN_FX * BN_RL) void s2g_k_bn_lrelu_bwd_fused(
+    const float* __restrict__ y, const float* __restrict__ dy, const float* __restrict__ xhat,
+    const float* __restrict__ gamma, const float* __restrict__ invstd, float* __restrict__ dgamma,
+    float* __restrict__ dbeta, float* __restrict__ dx, int B, int F) {
+  __shared__ float red[2][BN_RL][BN_FX];
+  const int fx = threadIdx.x % BN_FX, rl = threadIdx.x / BN_FX;
+  const int f = blockIdx.x * BN_FX + fx;
+  const bool live = f < F;
+  const int fc = live ? f : F - 1;
+  float s = 0.0f, q = 0.0f;
+  for (int b = rl; b < B; b += BN_RL) {
+    const long i = (long)b * F + fc;
+    const float d = y[i] > 0.0f ? dy[i] : 0.2f * dy[i];
+    s += d; q = fmaf(d, xhat[i], q);
+  }
+  red[0][rl][fx] = s; red[1][rl][fx] = q;
+  __syncthreads();
+  s = 0.0f; q = 0.0f;
+#pragma unroll
+  for (int r = 0; r < BN_RL; ++r) { s += red[0][r][fx]; q += red[1][r][fx]; }
+  if (!live) return;
+  if (rl == 0) { dbeta[f] = s; dgamma[f] = q; }
+  const float n = (float)B;
+  const float a = s / n, c = q / n, gi = gamma[f] * invstd[f];
+  for (int b = rl; b < B; b += BN_RL) {
+    const long i = (long)b * F + f;
+    const float d = y[i] > 0.0f ? dy[i] : 0.2f * dy[i];
+    dx[i] = gi * (d - a - xhat[i] * c);
   }
 }
 

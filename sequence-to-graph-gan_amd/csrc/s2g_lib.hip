@@ -253,7 +253,7 @@ int s2g_embed_mul(const float* z, const long long* labels, const float* emb, flo
 int s2g_embed_mul_bwd(const float* z, const long long* labels, const float* dout, float* demb, int B, int D,
                       int n_classes, void* stream) {
   if (!z || !labels || !dout || !demb || B <= 0 || D <= 0 || n_classes <= 0) return -1;
-  hipLaunchKernelGGL(s2g_k_embed_mul_bwd, dim3(cdiv((long)n_classes * D, 256)), dim3(256), 0, ST(stream), z,
+  hipLaunchKernelGGL(s2g_k_embed_mul_bwd, dim3(cdiv((long)n_classes * D * 16, 256)), dim3(256), 0, ST(stream), z,
                      labels, dout, demb, B, D, n_classes);
   return LAUNCH_OK();
 }
@@ -292,6 +292,22 @@ int s2g_bn_bwd_apply(const float* dyh, const float* xhat, const float* sums, flo
   if (!dyh || !xhat || !sums || !gamma || !invstd || !dx || B <= 0 || F <= 0 || !(n_global > 0.0f)) return -1;
   hipLaunchKernelGGL(s2g_k_bn_bwd_apply, dim3(cdiv(F, 64)), dim3(64), 0, ST(stream), dyh, xhat, sums, n_global,
                      gamma, invstd, dx, B, F);
+  return LAUNCH_OK();
+}
+int s2g_bn_lrelu_fwd_fused(const float* x, const float* gamma, const float* beta, float* run_mean, float* run_var,
+                           float eps, float momentum, int update_running, float* y, float* xhat, float* invstd,
+                           int B, int F, void* stream) {
+  if (!x || !gamma || !beta || !run_mean || !run_var || !y || !xhat || !invstd || B <= 0 || F <= 0) return -1;
+  hipLaunchKernelGGL(s2g_k_bn_lrelu_fwd_fused, dim3(cdiv(F, BN_FX)), dim3(BN_FX * BN_RL), 0, ST(stream), x, gamma,
+                     beta, run_mean, run_var, eps, momentum, update_running, y, xhat, invstd, B, F);
+  return LAUNCH_OK();
+}
+int s2g_bn_lrelu_bwd_fused(const float* y, const float* dy, const float* xhat, const float* gamma,
+                           const float* invstd, float* dgamma, float* dbeta, float* dx, int B, int F,
+                           void* stream) {
+  if (!y || !dy || !xhat || !gamma || !invstd || !dgamma || !dbeta || !dx || B <= 0 || F <= 0) return -1;
+  hipLaunchKernelGGL(s2g_k_bn_lrelu_bwd_fused, dim3(cdiv(F, BN_FX)), dim3(BN_FX * BN_RL), 0, ST(stream), y, dy, xhat,
+                     gamma, invstd, dgamma, dbeta, dx, B, F);
   return LAUNCH_OK();
 }
 

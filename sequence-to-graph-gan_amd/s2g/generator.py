@@ -67,6 +67,12 @@ class GeneratorEngine:
         invstd = torch.empty(F_, device=self.device) if training else None
         stats = None
         n_global = float(B * self.comm.world)
+        if training and self.comm.world == 1:
+            # one process: batch statistics need no all-reduce, statistics + normalise in one launch
+            call("s2g_bn_lrelu_fwd_fused", ptr(pre), ptr(p[name + ".weight"]), ptr(p[name + ".bias"]),
+                 ptr(self.buffers[name + ".running_mean"]), ptr(self.buffers[name + ".running_var"]), BN_EPS,
+                 BN_MOMENTUM, int(update_running), ptr(y), ptr(xhat), ptr(invstd), B, F_, stream_ptr())
+            return y, xhat, invstd
         if training:
             stats = torch.empty(2 * F_, device=self.device)
             call("s2g_bn_stats", ptr(pre), ptr(stats), B, F_, stream_ptr())
@@ -117,6 +123,11 @@ class GeneratorEngine:
     # ------------------------------------------------------------------ backward
     def _bn_bwd(self, a, da, xhat, inv, name, B, F_):
         g = self.grads.views
+        if self.comm.world == 1:
+            dpre = torch.empty_like(da)
+            call("s2g_bn_lrelu_bwd_fused", ptr(a), ptr(da), ptr(xhat), ptr(self.params.views[name + ".weight"]),
+                 ptr(inv), ptr(g[name + ".weight"]), ptr(g[name + ".bias"]), ptr(dpre), B, F_, stream_ptr())
+            return dpre
         sums = torch.empty(2 * F_, device=self.device)
         call("s2g_bn_lrelu_bwd_stats", ptr(a), ptr(da), ptr(xhat), ptr(sums), B, F_, stream_ptr())
         self.comm.allreduce(sums)

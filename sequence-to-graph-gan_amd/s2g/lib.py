@@ -71,6 +71,8 @@ SIGNATURES = {
     "s2g_bn_lrelu_apply": [P, P, F, P, P, P, P, F, F, I, P, P, P, I, I, P],
     "s2g_bn_lrelu_bwd_stats": [P, P, P, P, I, I, P],
     "s2g_bn_bwd_apply": [P, P, P, F, P, P, P, I, I, P],
+    "s2g_bn_lrelu_fwd_fused": [P, P, P, P, P, F, F, I, P, P, P, I, I, P],
+    "s2g_bn_lrelu_bwd_fused": [P, P, P, P, P, P, P, P, I, I, P],
     "s2g_adam": [P, P, P, P, L, F, F, F, F, I, F, P],
     "s2g_stream_create_cu_mask": [P, I, P],
     "s2g_stream_destroy": [P],

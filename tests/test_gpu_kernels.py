@@ -132,6 +132,71 @@ def test_critic_head_matches_separate_kernels(B):
         assert rel(a, b) < 1e-5
 
 
+@pytest.mark.parametrize("B,F", [(64, 256), (64, 512), (7, 50), (1, 33)])
+def test_bn_fused_matches_two_kernel_form(B, F):
+    """One-launch BatchNorm(eps=0.8)+LeakyReLU forward/backward (wgan_gp.py:150,156-157) against the
+    statistics + apply pair that data-parallel runs use, and against torch."""
+    from s2g.lib import call
+    from s2g.ops import ptr, stream_ptr
+    g = common.gen(30 + B)
+    x = torch.randn(B, F, generator=g).to(DEV) * 2 + 0.5
+    gamma = (torch.rand(F, generator=g) + 0.5).to(DEV)
+    beta = torch.randn(F, generator=g).to(DEV)
+    dy = torch.randn(B, F, generator=g).to(DEV)
+    st = stream_ptr()
+    outs = []
+    for fused in (False, True):
+        rm, rv = torch.zeros(F, device=DEV), torch.ones(F, device=DEV)
+        y, xhat, inv = torch.empty_like(x), torch.empty_like(x), torch.empty(F, device=DEV)
+        dgamma, dbeta, dx = torch.empty(F, device=DEV), torch.empty(F, device=DEV), torch.empty_like(x)
+        if fused:
+            call("s2g_bn_lrelu_fwd_fused", ptr(x), ptr(gamma), ptr(beta), ptr(rm), ptr(rv), 0.8, 0.1, 1, ptr(y),
+                 ptr(xhat), ptr(inv), B, F, st)
+            call("s2g_bn_lrelu_bwd_fused", ptr(y), ptr(dy), ptr(xhat), ptr(gamma), ptr(inv), ptr(dgamma), ptr(dbeta),
+                 ptr(dx), B, F, st)
+        else:
+            stats, sums, d = torch.empty(2 * F, device=DEV), torch.empty(2 * F, device=DEV), dy.clone()
+            call("s2g_bn_stats", ptr(x), ptr(stats), B, F, st)
+            call("s2g_bn_lrelu_apply", ptr(x), ptr(stats), float(B), ptr(gamma), ptr(beta), ptr(rm), ptr(rv), 0.8, 0.1,
+                 1, ptr(y), ptr(xhat), ptr(inv), B, F, st)
+            call("s2g_bn_lrelu_bwd_stats", ptr(y), ptr(d), ptr(xhat), ptr(sums), B, F, st)
+            call("s2g_bn_bwd_apply", ptr(d), ptr(xhat), ptr(sums), float(B), ptr(gamma), ptr(inv), ptr(dx), B, F, st)
+            dbeta, dgamma = sums[:F].clone(), sums[F:].clone()
+        torch.cuda.synchronize()
+        outs.append((y, xhat, inv, rm, rv, dgamma, dbeta, dx))
+    for a, b in zip(*outs):
+        assert torch.isfinite(b).all()
+        assert rel(b, a) < 1e-5
+    # torch on the same numbers (float64)
+    xd = x.double().cpu().requires_grad_(True)
+    bn = torch.nn.BatchNorm1d(F, 0.8).double()
+    with torch.no_grad():
+        bn.weight.copy_(gamma.double().cpu()); bn.bias.copy_(beta.double().cpu())
+    if B > 1:
+        yt = torch.nn.functional.leaky_relu(bn(xd), 0.2)
+        yt.backward(dy.double().cpu())
+        y, _, _, rm, rv, dgamma, dbeta, dx = outs[1]
+        for got, want in ((y, yt), (rm, bn.running_mean), (rv, bn.running_var), (dgamma, bn.weight.grad),
+                          (dbeta, bn.bias.grad), (dx, xd.grad)):
+            assert rel(got.cpu(), want.detach()) < TOL
+
+
+def test_embed_mul_bwd_matches_torch():
+    from s2g.lib import call
+    from s2g.ops import ptr, stream_ptr
+    g = common.gen(41)
+    for B in (64, 5, 1):
+        z = torch.randn(B, 100, generator=g).to(DEV)
+        dout = torch.randn(B, 100, generator=g).to(DEV)
+        labels = torch.randint(0, 2, (B,), generator=g).to(DEV)
+        demb = torch.full((2, 100), float("nan"), device=DEV)
+        call("s2g_embed_mul_bwd", ptr(z), ptr(labels), ptr(dout), ptr(demb), B, 100, 2, stream_ptr())
+        torch.cuda.synchronize()
+        want = torch.zeros(2, 100, dtype=torch.float64)
+        want.index_add_(0, labels.cpu(), (z.double() * dout.double()).cpu())
+        assert (demb.double().cpu() - want).abs().max() < 1e-4
+
+
 def test_cu_masked_stream_runs_kernels():
     from s2g import lib
     from s2g.lib import call
