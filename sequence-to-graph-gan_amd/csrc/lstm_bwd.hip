@@ -108,10 +108,19 @@ __device__ __forceinline__ void zero_tail(float* buf, int ws_row, int len, int T
 
 #define ISSUE_M(j, i_) { mk[j] = (pm + (unsigned)(max(min(len - (i_), len - 1), 0) * sm))[unit]; }
 
-// projection waves of both reverse sweeps: dy_t = mask_t * (W_ih1^T d1_t) -> dybuf
+// projection waves of both reverse sweeps: dy_t = mask_t * (W_ih1^T d1_t) -> dybuf.
+// With STORES (sweep D, whose cell waves have the shallower prefetch ring) waves 6 and 7 also write
+// the gate gradients of layer 1 / layer 0 to global memory, one step
+// behind the cell waves and out of the LDS vectors those publish anyway (out1/out0 = row 0 of this
+// sequence).  Loads and stores share one in-order completion counter per wave, so a store issued by
+// a cell wave would sit in front of every wait for its prefetched activations: measured, the
+// 16-byte store per step cost the second-order sweep a quarter of its time.  Here 50 lanes write
+// one full 800-byte row per step.
+template <bool STORES>
 __device__ __forceinline__ void reverse_projection(const S2GSeq& sq, const float* mask, const float* wih1,
-                                                   const float* dummy, const float* d1buf, float* dybuf, int wv,
-                                                   int lane, int nit) {
+                                                   const float* dummy, const float* d1buf, const float* d0buf,
+                                                   float* dybuf, float* out1, float* out0, int wv, int lane,
+                                                   int nit) {
   const int len = sq.len;
   const bool has_mask = sq.mask_off >= 0 && mask != nullptr;
   const int p = 8 * (wv - 4) + (lane >> 3), s = lane & 7;
@@ -122,6 +131,14 @@ __device__ __forceinline__ void reverse_projection(const S2GSeq& sq, const float
   load_wT_pair(wih1, pc, s, w);
   const float* pm = has_mask ? mask + (size_t)sq.mask_off * S2G_MASKW : dummy;
   const int sm = has_mask ? S2G_MASKW : 0;
+  // store duty: wave 6 -> layer 1 (its cell waves handled t = len-i one iteration ago), wave 7 ->
+  // layer 0 (t = len+2-i); lane = unit
+  const bool storer = STORES && wv >= 6 && lane < S2G_H;
+  const int su = lane < S2G_H ? lane : 0;
+  const float* sbuf = (wv == 6) ? d1buf : d0buf;
+  float* sout = ((wv == 6) ? out1 : out0) + 4 * su;
+  const int slag = (wv == 6) ? 0 : 2;
+  const int q0 = dpos(4 * su), q1 = dpos(4 * su + 1), q2 = dpos(4 * su + 2), q3 = dpos(4 * su + 3);
   __syncthreads();
   float mk[PF];
 #pragma unroll
@@ -132,14 +149,27 @@ __device__ __forceinline__ void reverse_projection(const S2GSeq& sq, const float
       const int i = base + j;
       if (i < nit) {
         const int t = len - i;
+        const int ts = t + slag;
+        float4 dv;
+        const bool st = storer && ts >= 0 && ts < len;
+        if (st) {
+          const float* b = sbuf + (ts & 1) * DVEC;
+          dv = make_float4(b[q0], b[q1], b[q2], b[q3]);
+        }
         if (t >= 0 && t < len) {
           const float dy = matvecT_pair(w, d1buf + (t & 1) * DVEC + 28 * s);
           if (owner) dybuf[(t & 1) * 64 + unit] = has_mask ? dy * mk[j] : dy;
         }
+        if (st) store_stream(sout + (unsigned)(ts * S2G_G), dv);
         __syncthreads();
       }
       ISSUE_M(j, i + PF)
     }
+  }
+  // layer 0's last step (t = 0) was published in the last iteration
+  if (STORES && wv == 7 && lane < S2G_H && len >= 1) {
+    const float* b = d0buf;
+    store_stream(sout, make_float4(b[q0], b[q1], b[q2], b[q3]));
   }
 }
 
@@ -176,7 +206,7 @@ extern "C" __global__ __launch_bounds__(BWD_THREADS) void s2g_k_lstm2_bwd(
   const int nit = len + 2;
 
   if (wv >= 4) {
-    reverse_projection(sq, mask, wih1, whh0, d1buf, dybuf, wv, lane, nit);
+    reverse_projection<false>(sq, mask, wih1, whh0, d1buf, d0buf, dybuf, nullptr, nullptr, wv, lane, nit);
   } else {
     // ---------------- cell waves: 0,1 = layer 1 (lag 0), 2,3 = layer 0 (lag 2) ----------------
     const bool top = wv < 2;
@@ -285,7 +315,8 @@ extern "C" __global__ __launch_bounds__(BWD_THREADS) void s2g_k_lstm2_bwd2(
   const int nit = len + 2;
 
   if (wv >= 4) {
-    reverse_projection(sq, mask, wih1, whh0, d1buf, dybuf, wv, lane, nit);
+    const size_t rb = (size_t)sq.ws_row * S2G_G;
+    reverse_projection<true>(sq, mask, wih1, whh0, d1buf, d0buf, dybuf, abar1 + rb, abar0 + rb, wv, lane, nit);
   } else {
     const bool top = wv < 2;
     const int lag = top ? 0 : 2;
@@ -303,7 +334,6 @@ extern "C" __global__ __launch_bounds__(BWD_THREADS) void s2g_k_lstm2_bwd2(
     const float* pa = (top ? adot1 : adot0) + rb;
     const float* pcd = (top ? celld1 : celld0) + rb;
     const float* pj = (top ? adj1 : adj0) + (size_t)sq.ws_row * (2 * S2G_H);
-    float* abar = (top ? abar1 : abar0) + rb;
     float* dbuf = top ? d1buf : d0buf;
     const int p0 = dpos(4 * uc), p1 = dpos(4 * uc + 1), p2 = dpos(4 * uc + 2), p3 = dpos(4 * uc + 3);
     __syncthreads();
@@ -351,7 +381,6 @@ extern "C" __global__ __launch_bounds__(BWD_THREADS) void s2g_k_lstm2_bwd2(
             cb = cbt * gf + Cd * fd;
             const float4 d = make_float4(ib * si, fb * sf, gb * sg, ob * so);
             if (owner) {
-              *reinterpret_cast<float4*>(abar + (unsigned)(t * S2G_G) + lo4) = d;
               float* db = dbuf + (t & 1) * DVEC;
               db[p0] = d.x; db[p1] = d.y; db[p2] = d.z; db[p3] = d.w;
             }

@@ -470,6 +470,9 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         (ptr(a1), n3, ptr(c1, oi + 2), G4, 4, Tw, Tw, Tw, True, 2),
         (ptr(d1, oi), n3, ptr(cd1, 1), G4, 4, Tw, Tw, Tw, True, 1)])]
     built = _wgrad_build(eng, jobs, ("critic", B, T, Tf, fake.data_ptr()))
+    side = eng.side() if eng.overlap else None
+    # recorded behind the phase-0 launch when the prefetch hook has a stream of its own to start from it
+    after_p0 = torch.cuda.Event() if (side is not None and prefetch is not None and eng.stream_g is not None) else None
 
     def first_order(sc):
         """Everything that needs sweeps A and B only: operands of the products, their phase-0 part, the
@@ -481,6 +484,10 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         call("s2g_one_hot", ptr(tokens), ptr(lengths), T, ptr(ws["xreal"]), B * T, V, s_)
         call("s2g_gp_interp", ptr(tokens), ptr(lengths), ptr(fake), ptr(alpha), B, T, Tf, V, ptr(ws["xhat"]), s_)
         _wgrad_launch(eng, built, 0)
+        if after_p0 is not None:
+            after_p0.record()
+
+    def first_order_sums(sc):
         ops.colsum(d0, n12, G4, G4, g["lstm.bias_ih_l0"], sc, permute_rows=True)
         ops.colsum(d1, n12, G4, G4, g["lstm.bias_ih_l1"], sc, permute_rows=True)
 
@@ -497,7 +504,6 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         g["lstm.bias_hh_l1"].copy_(g["lstm.bias_ih_l1"])
         ops.colsum(ws["hdotT"], B, H, H, g["fc.weight"][0], sc, accumulate=True)
 
-    side = eng.side() if eng.overlap else None
     if side is not None:
         # stream_c: sweep C, sweep D (B workgroups on the reserved quarter of the CUs), then the
         #           second-order column sums, which run beside the last products on the caller's stream
@@ -512,14 +518,17 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
             stream_c.wait_event(fork)
             eng.timed("s2g_k_lstm2_tangent", lambda: eng.sweep_tangent(ws, drel, B, mrel, r_int))
             after_c.record()
-        if prefetch is not None and eng.stream_g is not None:
-            # the hook's work (not part of the join) starts with the fork, on a masked stream of its own
+        if after_p0 is not None:
+            # the hook's work (not part of the join) goes to a masked stream of its own and starts once
+            # the big phase-0 launch is through: the short phase-1 launch and the small column sums that
+            # follow on stream2 leave the masked CUs mostly idle until sweep D ends
             with torch.cuda.stream(eng.stream_g):
-                eng.stream_g.wait_event(fork)
+                eng.stream_g.wait_event(after_p0)
                 prefetch()
         with torch.cuda.stream(stream2):
             stream2.wait_event(after_c)
-            _wgrad_launch(eng, built, 1)
+            _wgrad_launch(eng, built, 1)          # ahead of the small column sums: it must be through before D is
+            first_order_sums(sc2)
             join.record()
             if prefetch is not None and eng.stream_g is None:
                 prefetch()          # not part of the join: it may run on beside this iteration's tail
@@ -542,6 +551,7 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         eng.timed("s2g_k_lstm2_tangent", lambda: eng.sweep_tangent(ws, drel, B, mrel, r_int))
         eng.timed("s2g_k_lstm2_bwd2", lambda: eng.sweep_bwd2(ws, drel, B, Tw, mrel, r_int))
         first_order(sc)
+        first_order_sums(sc)
         _wgrad_launch(eng, built, 1)
         if prefetch is not None:
             prefetch()

@@ -29,7 +29,31 @@ def timeit(fn, reps=20):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
+_FLUSH = None
+
+
+def timeit_cold(fn, reps=10):
+    """Like timeit, but a 1 GiB fill between launches evicts the operands from L2 and the memory-side
+    cache first (inside a training step a sweep's inputs were written long before it reads them)."""
+    global _FLUSH
+    if _FLUSH is None:
+        _FLUSH = torch.empty(1 << 28, dtype=torch.float32, device="cuda:0")
+    tot = 0.0
+    for _ in range(reps):
+        _FLUSH.fill_(1.0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        tot += e0.elapsed_time(e1)
+    return tot / reps * 1e3
+
+
 def main():
+    global timeit
+    if "--cold" in sys.argv:
+        timeit = timeit_cold
     dev = torch.device("cuda:0")
     B, T, V = 64, 512, 175
     for a in sys.argv[1:]:
@@ -65,6 +89,7 @@ def main():
     res["fwd_192"] = timeit(lambda: eng.sweep_fwd(ws, ptr(desc), 3 * B, T, tok, P, mask))
     res["fwd_64"] = timeit(lambda: eng.sweep_fwd(ws, ptr(desc), B, T, tok, P, mask))
     res["bwd_192"] = timeit(lambda: eng.sweep_bwd(ws, ptr(desc), 3 * B, T, mask, adj_seq0=2 * B))
+    res["bwd_64"] = timeit(lambda: eng.sweep_bwd(ws, ptr(desc), B, T, mask))
     res["tangent_64"] = timeit(lambda: eng.sweep_tangent(ws, ptr(desc, 3 * B * 8), B, mrel, r0))
     res["bwd2_64"] = timeit(lambda: eng.sweep_bwd2(ws, ptr(desc, 3 * B * 8), B, T, mrel, r0))
     print(f"T={T} per-step ns:", " ".join(f"{k}={v * 1e3 / (T + 2):.0f}" for k, v in res.items()))
