@@ -366,20 +366,38 @@ extern "C" __global__ __launch_bounds__(BWD_THREADS) void s2g_k_lstm2_bwd2(
             if (!top) hb += dybuf[(t & 1) * 64 + uc];
             const float cprev = (t > 0) ? rc[(j + 1) % PFD].x : 0.0f;   // slot of the next iteration = step t-1
             const float cdprev = (t > 0) ? rcd[(j + 1) % PFD] : 0.0f;
-            const float gi = rg[j].x, gf = rg[j].y, gg = rg[j].z, go = rg[j].w, tc = rc[j].y;
-            const float ai = ra[j].x, af = ra[j].y, ag = ra[j].z, ao = ra[j].w;
-            const float cd = rcd[j], Hd = rj[j].x, Cd = rj[j].y;
-            const float si = gi * (1.0f - gi), sf = gf * (1.0f - gf), sg = 1.0f - gg * gg, so = go * (1.0f - go);
-            const float id_ = si * ai, fd = sf * af, gd = sg * ag, od = so * ao;
-            const float uu = 1.0f - tc * tc;
-            const float tcb = Hd * (od - 2.0f * go * tc * cd) + hb * go;
-            const float ob = Hd * uu * cd + hb * tc + Hd * tc * (1.0f - 2.0f * go) * ao;
-            const float cbt = cb + tcb * uu;
-            const float fb = Cd * cdprev + cbt * cprev + Cd * cprev * (1.0f - 2.0f * gf) * af;
-            const float ib = Cd * gd + cbt * gg + Cd * gg * (1.0f - 2.0f * gi) * ai;
-            const float gb = Cd * id_ + cbt * gi + Cd * gi * (-2.0f * gg) * ag;
-            cb = cbt * gf + Cd * fd;
-            const float4 d = make_float4(ib * si, fb * sf, gb * sg, ob * so);
+            // Second-order cell backward, two gates per packed instruction.  With s = gate derivative
+            // factors, X' = gate tangents, (Hd, Cd) = adjoints of the tangent states:
+            //   tcb = Hd (od - 2 go tc cd) + hb go                  (adjoint of tanh c)
+            //   cbt = cb + tcb (1 - tc^2)
+            //   ib  = Cd gd     + cbt gg    + Cd gg    (1 - 2 gi) ai
+            //   fb  = Cd cdprev + cbt cprev + Cd cprev (1 - 2 gf) af
+            //   gb  = Cd id     + cbt gi    + Cd gi    (-2 gg)    ag
+            //   ob  = Hd uu cd  + hb  tc    + Hd tc    (1 - 2 go) ao
+            // i.e. r = K (X + Y M A) + S Y for the pairs (ib, fb) and (gb, ob); everything but the S Y
+            // term is independent of this step's mat-vec.
+            const float tc = rc[j].y, cd = rcd[j], Hd = rj[j].x, Cd = rj[j].y;
+            const f2 G01 = {rg[j].x, rg[j].y}, G23 = {rg[j].z, rg[j].w};      // (gi, gf), (gg, go)
+            const f2 A01 = {ra[j].x, ra[j].y}, A23 = {ra[j].z, ra[j].w};      // (ai, af), (ag, ao)
+            const f2 S01 = __builtin_elementwise_fma(-G01, G01, G01);          // (si, sf) = g (1 - g)
+            const f2 S23 = __builtin_elementwise_fma(-G23, G23, (f2){1.0f, G23.y});   // (1 - gg^2, go (1 - go))
+            const f2 D01 = S01 * A01, D23 = S23 * A23;                         // (id, fd), (gd, od)
+            const float uu = fmaf(-tc, tc, 1.0f);
+            const float tcb_pre = Hd * fmaf(-2.0f * (G23.y * tc), cd, D23.y);
+            const f2 Y1 = {G23.x, cprev}, Y2 = {G01.x, tc};
+            const f2 M1 = __builtin_elementwise_fma((f2){-2.0f, -2.0f}, G01, (f2){1.0f, 1.0f});
+            const f2 M2 = __builtin_elementwise_fma((f2){-2.0f, -2.0f}, G23, (f2){0.0f, 1.0f});
+            const f2 pre1 = (f2){Cd, Cd} * __builtin_elementwise_fma(Y1 * M1, A01, (f2){D23.x, cdprev});
+            const f2 pre2 = (f2){Cd, Hd} * __builtin_elementwise_fma(Y2 * M2, A23, (f2){D01.x, uu * cd});
+            const float cb_pre = Cd * D01.y;
+            // ---- the part behind the mat-vec
+            const float tcb = fmaf(hb, G23.y, tcb_pre);
+            const float cbt = fmaf(tcb, uu, cb);
+            const f2 r1 = __builtin_elementwise_fma((f2){cbt, cbt}, Y1, pre1);   // (ib, fb)
+            const f2 r2 = __builtin_elementwise_fma((f2){cbt, hb}, Y2, pre2);    // (gb, ob)
+            cb = fmaf(cbt, G01.y, cb_pre);
+            const f2 d01 = r1 * S01, d23 = r2 * S23;
+            const float4 d = make_float4(d01.x, d01.y, d23.x, d23.y);
             if (owner) {
               float* db = dbuf + (t & 1) * DVEC;
               db[p0] = d.x; db[p1] = d.y; db[p2] = d.z; db[p3] = d.w;
