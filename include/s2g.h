@@ -101,10 +101,24 @@ int s2g_lstm2_fwd(const S2GSeq* seqs, int nseq, int max_len, const int* tokens, 
  * autograd.grad(..., inputs=interpolates) (:247-254) run through the LSTM.  adj0/adj1 may be NULL;
  * otherwise sequences n >= adj_seq0 store (dh_t, dc_t) at adj row (ws_row + t - adj_row0).
  * rows_per_seq: workspace rows reserved per sequence (rows >= len are zero-filled in delta*). */
+/* head (optional, a HOST struct): sweep B evaluates the fc head (wgan_gp.py:221) and the derivative of
+ * the loss terms (wgan_gp.py:299-313 / 333-340) of each sequence itself and ignores dhT, so that no
+ * launch sits between the forward and the reverse sweep.  mode 0: nseq = 3B laid out
+ * [real B | fake B | interp B] with d(out) = (-inv_n, .5 dCE), (+inv_n, .5 dCE), (1, 0, 0);
+ * mode 1: nseq = B fakes of the generator pass, d(out) = (-inv_n, .25 dCE). */
+typedef struct S2GHead {
+  const float* hT;          /* [nseq, 50] final hidden states written by s2g_lstm2_fwd */
+  const float* W;           /* fc.weight [3, 50] */
+  const float* bias;        /* fc.bias [3] */
+  const long long* labels;  /* [B] */
+  int B, mode;
+  float inv_n, inv_wsum, w0, w1;
+} S2GHead;
 int s2g_lstm2_bwd(const S2GSeq* seqs, int nseq, int rows_per_seq, const float* mask, const float* whh0,
                   const float* wih1, const float* whh1, const float* gates0, const float* cell0,
                   const float* gates1, const float* cell1, const float* dhT, float* delta0, float* delta1,
-                  float* adj0, float* adj1, int adj_seq0, int adj_row0, void* stream);
+                  float* adj0, float* adj1, int adj_seq0, int adj_row0, const struct S2GHead* head,
+                  void* stream);
 /* tangent (forward-mode) sweep along an input direction whose projection is Xdot [rows, 200];
  * with s2g_lstm2_bwd2 it replaces the double backward that create_graph=True makes autograd
  * run for the gradient penalty (wgan_gp.py:251, 256, 317). */

@@ -437,24 +437,6 @@ extern "C" __global__ void s2g_k_head_bwd_w(const float* __restrict__ dout, cons
   if (k == 0) db[j] = accumulate ? db[j] + sb : sb;
 }
 
-// CrossEntropyLoss(weight=[w0,w1]) applied to p = softmax(z) (probabilities fed as logits, the
-// reference's double softmax, wgan_gp.py:268,299,310): per-sample value and d/dz.
-__device__ __forceinline__ void ce_on_probs(float z0, float z1, int y, float w0, float w1, float inv_wsum,
-                                            float& loss, float& dz0, float& dz1) {
-  float m = fmaxf(z0, z1);
-  float e0 = expf(z0 - m), e1 = expf(z1 - m);
-  float p0 = e0 / (e0 + e1), p1 = e1 / (e0 + e1);
-  float m2 = fmaxf(p0, p1);
-  float f0 = expf(p0 - m2), f1 = expf(p1 - m2);
-  float lse = m2 + logf(f0 + f1);
-  float s0 = f0 / (f0 + f1), s1 = f1 / (f0 + f1);        // softmax(p)
-  float wy = (y == 0 ? w0 : w1) * inv_wsum;
-  loss = wy * (lse - (y == 0 ? p0 : p1));
-  float dp0 = wy * (s0 - (y == 0 ? 1.0f : 0.0f)), dp1 = wy * (s1 - (y == 1 ? 1.0f : 0.0f));
-  float dot = dp0 * p0 + dp1 * p1;
-  dz0 = p0 * (dp0 - dot);
-  dz1 = p1 * (dp1 - dot);
-}
 
 // Critic loss terms and d(out) for a batch laid out [real B | fake B | interp B]
 // (wgan_gp.py:298-315).  out: [3B,3].  inv_n = 1/B_global, inv_wsum = 1/sum_b w[y_b] (global).

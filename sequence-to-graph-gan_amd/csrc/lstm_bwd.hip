@@ -184,7 +184,7 @@ extern "C" __global__ __launch_bounds__(BWD_THREADS) void s2g_k_lstm2_bwd(
     const float* __restrict__ wih1, const float* __restrict__ whh1, const float* __restrict__ gates0,
     const float* __restrict__ cell0, const float* __restrict__ gates1, const float* __restrict__ cell1,
     const float* __restrict__ dhT, float* __restrict__ delta0, float* __restrict__ delta1,
-    float* __restrict__ adj0, float* __restrict__ adj1, int T, int adj_seq0, int adj_row0) {
+    float* __restrict__ adj0, float* __restrict__ adj1, int T, int adj_seq0, int adj_row0, S2GHead head) {
   __shared__ __attribute__((aligned(16))) float lds[4 * DVEC + 128];
   float* d1buf = lds;                // delta of layer 1 [2][DVEC]
   float* d0buf = lds + 2 * DVEC;     // delta of layer 0 [2][DVEC]
@@ -227,7 +227,34 @@ extern "C" __global__ __launch_bounds__(BWD_THREADS) void s2g_k_lstm2_bwd(
     float* adj = (adj0 != nullptr && n >= adj_seq0)
                      ? (top ? adj1 : adj0) + ((size_t)sq.ws_row - adj_row0) * (2 * S2G_H) : nullptr;
     float* dbuf = top ? d1buf : d0buf;
-    const float dh_final = (top && valid) ? dhT[(size_t)n * S2G_H + u] : 0.0f;
+    float dh_final = 0.0f;
+    if (top) {
+      if (head.hT != nullptr) {
+        // fc head + loss derivative of this sequence, so that nothing sits between sweeps A and B
+        // (all addresses are wave-uniform; same arithmetic as s2g_k_critic_head)
+        const float* hrow = head.hT + (size_t)n * S2G_H;
+        float o0 = head.bias[0], o1 = head.bias[1], o2 = head.bias[2];
+        for (int k = 0; k < S2G_H; ++k) {
+          const float hk = hrow[k];
+          o0 = fmaf(head.W[k], hk, o0);
+          o1 = fmaf(head.W[S2G_H + k], hk, o1);
+          o2 = fmaf(head.W[2 * S2G_H + k], hk, o2);
+        }
+        const int kind = head.mode == 1 ? 3 : n / head.B;      // 0 real, 1 fake, 2 interp, 3 generator pass
+        float e0 = 1.0f, e1 = 0.0f, e2 = 0.0f;
+        if (kind != 2) {
+          float l, c0, c1;
+          ce_on_probs(o1, o2, (int)head.labels[n % head.B], head.w0, head.w1, head.inv_wsum, l, c0, c1);
+          const float sc = kind == 3 ? 0.25f : 0.5f;
+          e0 = kind == 1 ? head.inv_n : -head.inv_n;
+          e1 = sc * c0;
+          e2 = sc * c1;
+        }
+        dh_final = valid ? fmaf(e2, head.W[2 * S2G_H + u], fmaf(e1, head.W[S2G_H + u], e0 * head.W[u])) : 0.0f;
+      } else {
+        dh_final = valid ? dhT[(size_t)n * S2G_H + u] : 0.0f;
+      }
+    }
     const int p0 = dpos(4 * uc), p1 = dpos(4 * uc + 1), p2 = dpos(4 * uc + 2), p3 = dpos(4 * uc + 3);
     __syncthreads();
 

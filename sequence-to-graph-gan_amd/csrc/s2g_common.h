@@ -23,6 +23,39 @@ struct S2GSeq {
   int ws_row;     // first row of this sequence in every workspace
 };
 
+// The fc head of the critic and the loss derivative for one sequence, evaluated by sweep B itself
+// (hT == nullptr: sweep B takes d loss / d h_T from its dhT argument instead).
+// mode 0: critic batch [real B | fake B | interp B]: d(out) = (-inv_n, .5 dCE), (+inv_n, .5 dCE), (1, 0, 0);
+// mode 1: generator pass on fakes: d(out) = (-inv_n, .25 dCE).
+struct S2GHead {
+  const float* hT;            // [nseq, 50] final hidden states of sweep A
+  const float* W;             // fc.weight [3, 50]
+  const float* bias;          // fc.bias [3]
+  const long long* labels;    // [B]
+  int B;
+  int mode;
+  float inv_n, inv_wsum, w0, w1;
+};
+
+// CrossEntropyLoss(weight=[w0,w1]) applied to p = softmax(z) (probabilities fed as logits, the
+// reference's double softmax, wgan_gp.py:268,299,310): per-sample value and d/dz.
+__device__ __forceinline__ void ce_on_probs(float z0, float z1, int y, float w0, float w1, float inv_wsum,
+                                            float& loss, float& dz0, float& dz1) {
+  float m = fmaxf(z0, z1);
+  float e0 = expf(z0 - m), e1 = expf(z1 - m);
+  float p0 = e0 / (e0 + e1), p1 = e1 / (e0 + e1);
+  float m2 = fmaxf(p0, p1);
+  float f0 = expf(p0 - m2), f1 = expf(p1 - m2);
+  float lse = m2 + logf(f0 + f1);
+  float s0 = f0 / (f0 + f1), s1 = f1 / (f0 + f1);        // softmax(p)
+  float wy = (y == 0 ? w0 : w1) * inv_wsum;
+  loss = wy * (lse - (y == 0 ? p0 : p1));
+  float dp0 = wy * (s0 - (y == 0 ? 1.0f : 0.0f)), dp1 = wy * (s1 - (y == 1 ? 1.0f : 0.0f));
+  float dot = dp0 * p0 + dp1 * p1;
+  dz0 = p0 * (dp0 - dot);
+  dz1 = p1 * (dp1 - dot);
+}
+
 // ---- DPP cross-lane helpers (64-wide wave, 16-lane DPP rows) ---------------------------------
 #define DPP_QUAD(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
 #define DPP_ROW_MIRROR 0x140

@@ -112,13 +112,21 @@ int s2g_lstm2_fwd(const S2GSeq* seqs, int nseq, int max_len, const int* tokens, 
 int s2g_lstm2_bwd(const S2GSeq* seqs, int nseq, int rows_per_seq, const float* mask, const float* whh0,
                   const float* wih1, const float* whh1, const float* gates0, const float* cell0,
                   const float* gates1, const float* cell1, const float* dhT, float* delta0, float* delta1,
-                  float* adj0, float* adj1, int adj_seq0, int adj_row0, void* stream) {
+                  float* adj0, float* adj1, int adj_seq0, int adj_row0, const S2GHead* head, void* stream) {
   if (!seqs || nseq <= 0 || rows_per_seq <= 0) return -1;
-  if (!whh0 || !wih1 || !whh1 || !gates0 || !cell0 || !gates1 || !cell1 || !dhT || !delta0 || !delta1) return -1;
+  if (!whh0 || !wih1 || !whh1 || !gates0 || !cell0 || !gates1 || !cell1 || !delta0 || !delta1) return -1;
   if ((adj0 == nullptr) != (adj1 == nullptr)) return -1;
   if (adj0 && (adj_seq0 < 0 || adj_row0 < 0)) return -1;
+  S2GHead h = {};
+  if (head) {
+    h = *head;
+    if (!h.hT || !h.W || !h.bias || !h.labels || h.B <= 0 || (h.mode != 0 && h.mode != 1)) return -1;
+    if (h.mode == 0 ? nseq != 3 * h.B : nseq != h.B) return -1;
+  } else if (!dhT) {
+    return -1;
+  }
   hipLaunchKernelGGL(s2g_k_lstm2_bwd, dim3(nseq), dim3(BWD_THREADS), 0, ST(stream), seqs, mask, whh0, wih1, whh1, gates0,
-                     cell0, gates1, cell1, dhT, delta0, delta1, adj0, adj1, rows_per_seq, adj_seq0, adj_row0);
+                     cell0, gates1, cell1, dhT, delta0, delta1, adj0, adj1, rows_per_seq, adj_seq0, adj_row0, h);
   return LAUNCH_OK();
 }
 

@@ -6,12 +6,13 @@ parameter), their packed copies, and the workspaces of the four LSTM sweeps; eve
 produced by kernels of libs2g (see include/s2g.h), torch only provides the memory."""
 from __future__ import annotations
 
+import ctypes
 from typing import Dict, Optional
 
 import torch
 
 from . import ops
-from .lib import S2GError, call
+from .lib import S2GError, S2GHead, call
 from .ops import G4, H, MASKW, ptr, stream_ptr
 
 CRITIC_SHAPES = lambda V: [  # noqa: E731  (state_dict order of the reference Discriminator)
@@ -236,15 +237,22 @@ class CriticEngine:
         call("s2g_head_fwd", ptr(ws["hT"]), ptr(p["fc.weight"]), ptr(p["fc.bias"]), ptr(ws["out"]), nseq, 3,
              stream_ptr())
 
-    def sweep_bwd(self, ws, desc_ptr, nseq, Tw, mask, adj_seq0: int = -1) -> None:
+    def head_args(self, ws, labels, B, mode, inv_n, inv_wsum, class_w) -> S2GHead:
+        """The fc head + loss derivative sweep B evaluates per sequence (mode 0: critic batch, 1: generator pass)."""
+        p = self.params.views
+        return S2GHead(ptr(ws["hT"]), ptr(p["fc.weight"]), ptr(p["fc.bias"]), ptr(labels), B, mode, inv_n, inv_wsum,
+                       class_w[0], class_w[1])
+
+    def sweep_bwd(self, ws, desc_ptr, nseq, Tw, mask, adj_seq0: int = -1, head: Optional[S2GHead] = None) -> None:
         """adj_seq0 >= 0: sequences [adj_seq0, nseq) also store (dh, dc) into the compact adj0/adj1
-        buffers (their row 0 = first workspace row of sequence adj_seq0)."""
+        buffers (their row 0 = first workspace row of sequence adj_seq0).
+        head: the sweep derives d loss / d h_T itself from ws["hT"] (head_args) instead of reading ws["dhT"]."""
         whh0, wih1, whh1 = self._w()
         store = adj_seq0 >= 0
         call("s2g_lstm2_bwd", desc_ptr, nseq, Tw, ptr(mask), whh0, wih1, whh1, ptr(ws["gates0"]), ptr(ws["cell0"]),
              ptr(ws["gates1"]), ptr(ws["cell1"]), ptr(ws["dhT"]), ptr(ws["delta0"]), ptr(ws["delta1"]),
              ptr(ws["adj0"]) if store else None, ptr(ws["adj1"]) if store else None,
-             max(adj_seq0, 0), max(adj_seq0, 0) * Tw, stream_ptr())
+             max(adj_seq0, 0), max(adj_seq0, 0) * Tw, ctypes.byref(head) if head is not None else None, stream_ptr())
 
     def sweep_tangent(self, ws, desc_ptr, nseq, mask_ptr, row0: int) -> None:
         """Sequences of `desc` count rows from workspace row `row0` (their descriptors are relative)."""
@@ -423,19 +431,27 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
     eng.project(fake, ws["Pf"])
     eng.timed("s2g_k_lstm2_fwd", lambda: eng.sweep_fwd(ws, dptr, 3 * B, Tw, tokens, ws["Pf"], mask))
     inv_n = 1.0 / float(n_global)
-    if B <= 1024:
-        # head, loss, d(out), d(hT) and the fc gradients in one single-workgroup launch
-        call("s2g_critic_head", ptr(ws["hT"]), ptr(p["fc.weight"]), ptr(p["fc.bias"]), ptr(labels), B, inv_n,
-             inv_wsum, class_w[0], class_w[1], ptr(ws["out"]), ptr(ws["dout"]), ptr(ws["losses"]), ptr(ws["dhT"]),
-             ptr(g["fc.weight"]), ptr(g["fc.bias"]), st)
-    else:
-        eng.head_fwd(ws, 3 * B)
-        call("s2g_critic_loss", ptr(ws["out"]), ptr(labels), B, inv_n, inv_wsum, class_w[0], class_w[1],
-             ptr(ws["dout"]), ptr(ws["losses"]), st)
-        call("s2g_head_bwd_dh", ptr(ws["dout"]), ptr(p["fc.weight"]), ptr(ws["dhT"]), 3 * B, 3, st)
-        call("s2g_head_bwd_w", ptr(ws["dout"]), ptr(ws["hT"]), ptr(g["fc.weight"]), ptr(g["fc.bias"]), 2 * B, 3, 0, st)
+
+    def head_losses():
+        """Loss values, d(out) and the fc gradients (wgan_gp.py:221, 299-313).  Sweep B derives its own
+        d loss / d h_T per sequence (head_args), so this bookkeeping runs off the critical path."""
+        s_ = stream_ptr()
+        if B <= 1024:
+            # head, loss, d(out), d(hT) and the fc gradients in one single-workgroup launch
+            call("s2g_critic_head", ptr(ws["hT"]), ptr(p["fc.weight"]), ptr(p["fc.bias"]), ptr(labels), B, inv_n,
+                 inv_wsum, class_w[0], class_w[1], ptr(ws["out"]), ptr(ws["dout"]), ptr(ws["losses"]),
+                 ptr(ws["dhT"]), ptr(g["fc.weight"]), ptr(g["fc.bias"]), s_)
+        else:
+            eng.head_fwd(ws, 3 * B)
+            call("s2g_critic_loss", ptr(ws["out"]), ptr(labels), B, inv_n, inv_wsum, class_w[0], class_w[1],
+                 ptr(ws["dout"]), ptr(ws["losses"]), s_)
+            call("s2g_head_bwd_dh", ptr(ws["dout"]), ptr(p["fc.weight"]), ptr(ws["dhT"]), 3 * B, 3, s_)
+            call("s2g_head_bwd_w", ptr(ws["dout"]), ptr(ws["hT"]), ptr(g["fc.weight"]), ptr(g["fc.bias"]), 2 * B, 3,
+                 0, s_)
+
     # sweep B on 3B sequences (the interp third with d(out) = e0 and stored adjoints)
-    eng.timed("s2g_k_lstm2_bwd", lambda: eng.sweep_bwd(ws, dptr, 3 * B, Tw, mask, adj_seq0=2 * B))
+    head = eng.head_args(ws, labels, B, 0, inv_n, inv_wsum, class_w)
+    eng.timed("s2g_k_lstm2_bwd", lambda: eng.sweep_bwd(ws, dptr, 3 * B, Tw, mask, adj_seq0=2 * B, head=head))
     # Penalty of the interp third (wgan_gp.py:247-256).  With g_t = W_ih0^T delta0_t the norm is
     # |g_b|^2 = sum_t delta0_t . (M2 delta0_t), M2 = W_ih0 W_ih0^T, and the projected direction the
     # tangent sweep consumes is coef_b * M2 delta0_t: one 200x200 product on the critical path.  The
@@ -471,8 +487,6 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         (ptr(d1, oi), n3, ptr(cd1, 1), G4, 4, Tw, Tw, Tw, True, 1)])]
     built = _wgrad_build(eng, jobs, ("critic", B, T, Tf, fake.data_ptr()))
     side = eng.side() if eng.overlap else None
-    # recorded behind the phase-0 launch when the prefetch hook has a stream of its own to start from it
-    after_p0 = torch.cuda.Event() if (side is not None and prefetch is not None and eng.stream_g is not None) else None
 
     def first_order(sc):
         """Everything that needs sweeps A and B only: operands of the products, their phase-0 part, the
@@ -484,8 +498,6 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         call("s2g_one_hot", ptr(tokens), ptr(lengths), T, ptr(ws["xreal"]), B * T, V, s_)
         call("s2g_gp_interp", ptr(tokens), ptr(lengths), ptr(fake), ptr(alpha), B, T, Tf, V, ptr(ws["xhat"]), s_)
         _wgrad_launch(eng, built, 0)
-        if after_p0 is not None:
-            after_p0.record()
 
     def first_order_sums(sc):
         ops.colsum(d0, n12, G4, G4, g["lstm.bias_ih_l0"], sc, permute_rows=True)
@@ -510,39 +522,60 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         # stream2 : products of phase 0 beside sweep C, products of phase 1 beside sweep D
         stream2, stream_c, fork, after_c, join, join_c, sc2 = side
         cur = torch.cuda.current_stream()
+        # The chain A -> B -> penalty -> C -> D -> last products is the critical path: it stays on ONE
+        # stream (every hop to another stream costs ~10 us of event latency), the caller's if that is a
+        # non-blocking stream.  On the NULL stream the sweeps move to stream_c instead, because the
+        # masked streams are blocking streams and would serialise with every launch there.
+        own = cur.cuda_stream != 0
+        sweeps = cur if own else stream_c
         fork.record()
         with torch.cuda.stream(stream2):
             stream2.wait_event(fork)
             first_order(sc2)
-        with torch.cuda.stream(stream_c):
-            stream_c.wait_event(fork)
+        with torch.cuda.stream(sweeps):
+            if not own:
+                stream_c.wait_event(fork)
             eng.timed("s2g_k_lstm2_tangent", lambda: eng.sweep_tangent(ws, drel, B, mrel, r_int))
             after_c.record()
-        if after_p0 is not None:
-            # the hook's work (not part of the join) goes to a masked stream of its own and starts once
-            # the big phase-0 launch is through: the short phase-1 launch and the small column sums that
-            # follow on stream2 leave the masked CUs mostly idle until sweep D ends
-            with torch.cuda.stream(eng.stream_g):
-                eng.stream_g.wait_event(after_p0)
+        # the small launch-bound pieces (loss values + fc gradients, first-order bias sums) go beside the
+        # operand / product chain of stream2, which must be through before sweep D is
+        small = eng.stream_g if eng.stream_g is not None else stream2
+        join_g = torch.cuda.Event()
+        with torch.cuda.stream(small):
+            small.wait_event(fork)
+            head_losses()
+            first_order_sums(sc2)
+            join_g.record()
+            if prefetch is not None and eng.stream_g is not None:
+                # the hook's work (not part of the join) follows on this masked stream of its own: started
+                # here it is through before sweep D is (started behind the phase-0 launch it ran into the
+                # iteration's tail: 2 % slower, measured on one box)
                 prefetch()
         with torch.cuda.stream(stream2):
             stream2.wait_event(after_c)
-            _wgrad_launch(eng, built, 1)          # ahead of the small column sums: it must be through before D is
-            first_order_sums(sc2)
+            _wgrad_launch(eng, built, 1)
             join.record()
             if prefetch is not None and eng.stream_g is None:
                 prefetch()          # not part of the join: it may run on beside this iteration's tail
-        with torch.cuda.stream(stream_c):
+        if idle is not None and own:
+            with torch.cuda.stream(stream_c):      # free while the sweeps run on the caller's stream
+                stream_c.wait_event(fork)
+                idle()
+        with torch.cuda.stream(sweeps):
             after_d = torch.cuda.Event()
             eng.timed("s2g_k_lstm2_bwd2", lambda: eng.sweep_bwd2(ws, drel, B, Tw, mrel, r_int))
             after_d.record()
-        if idle is not None:
+        if idle is not None and not own:
             idle()
-        cur.wait_event(after_d)
+        if not own:
+            cur.wait_event(after_d)
         cur.wait_event(join)
+        cur.wait_event(join_g)
         _wgrad_launch(eng, built, 2)
         with torch.cuda.stream(stream_c):
-            stream_c.wait_event(join)        # the first-order bias sums these accumulate onto
+            if own:
+                stream_c.wait_event(after_d)
+            stream_c.wait_event(join_g)      # the first-order bias sums and fc gradients these accumulate onto
             second_order_sums()
             join_c.record()
         _wgrad_reduce(eng, built)
@@ -550,6 +583,7 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
     else:
         eng.timed("s2g_k_lstm2_tangent", lambda: eng.sweep_tangent(ws, drel, B, mrel, r_int))
         eng.timed("s2g_k_lstm2_bwd2", lambda: eng.sweep_bwd2(ws, drel, B, Tw, mrel, r_int))
+        head_losses()
         first_order(sc)
         first_order_sums(sc)
         _wgrad_launch(eng, built, 1)
@@ -580,10 +614,26 @@ def critic_forward_backward_fake(eng: CriticEngine, fake: torch.Tensor, labels: 
     ws["desc"], ws["desc_key"] = desc, (B, Tf, mask is not None)
     eng.project(fake, ws["Pf"])
     eng.sweep_fwd(ws, ptr(desc), B, Tf, None, ws["Pf"], mask)
-    eng.head_fwd(ws, B)
-    call("s2g_generator_loss", ptr(ws["out"]), ptr(labels), B, 1.0 / float(n_global), inv_wsum, class_w[0],
-         class_w[1], ptr(ws["dout"]), ptr(ws["losses"]), st)
-    call("s2g_head_bwd_dh", ptr(ws["dout"]), ptr(p["fc.weight"]), ptr(ws["dhT"]), B, 3, st)
-    eng.sweep_bwd(ws, ptr(desc), B, Tf, mask)
+    # the reverse sweep derives d loss / d h_T per sequence itself; the loss values follow behind it
+    head = eng.head_args(ws, labels, B, 1, 1.0 / float(n_global), inv_wsum, class_w)
+
+    def loss_values():
+        eng.head_fwd(ws, B)
+        call("s2g_generator_loss", ptr(ws["out"]), ptr(labels), B, 1.0 / float(n_global), inv_wsum, class_w[0],
+             class_w[1], ptr(ws["dout"]), ptr(ws["losses"]), stream_ptr())
+
+    side = eng.side() if eng.overlap else None
+    if side is not None:
+        fwd_done, vals_done = torch.cuda.Event(), torch.cuda.Event()
+        fwd_done.record()
+        with torch.cuda.stream(side[1]):          # beside the reverse sweep
+            side[1].wait_event(fwd_done)
+            loss_values()
+            vals_done.record()
+    eng.sweep_bwd(ws, ptr(desc), B, Tf, mask, head=head)
     ops.gemm_tall(ptr(ws["delta0"]), G4, ptr(eng.W0p), eng.Vp, ptr(ws["dfake"]), V, B * Tf, V, G4)
+    if side is not None:
+        torch.cuda.current_stream().wait_event(vals_done)
+    else:
+        loss_values()
     return ws["losses"], ws["dfake"].view(B, Tf, V)

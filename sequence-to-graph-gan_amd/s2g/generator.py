@@ -106,13 +106,13 @@ class GeneratorEngine:
         if training:
             self.num_batches_tracked += 1
         logits = torch.empty(B, self.L * self.V, device=dev)
+        mode = ops.MODES.get(act, 2)
+        if mode == 0 and U is None:
+            U = torch.rand(B, self.L, self.V, device=dev)      # noise draw only; the sampler is the kernel
         if self.last_layer_ready is not None:
             # the output Linear's update may still be running on another stream (trainer._generator_step)
             torch.cuda.current_stream().wait_event(self.last_layer_ready)
         ops.linear_fwd(a3, p["model.8.weight"], p["model.8.bias"], logits)
-        mode = ops.MODES.get(act, 2)
-        if mode == 0 and U is None:
-            U = torch.rand(B, self.L, self.V, device=dev)      # noise draw only; the sampler is the kernel
         y, y_soft = ops.gumbel_softmax_fwd(logits.view(B, self.L, self.V), U if mode == 0 else None, tau, mode,
                                            hard, out=out)
         if save:

@@ -29,6 +29,11 @@ class S2GGemm(ctypes.Structure):
                 ("a_seg", I), ("b_seg", I), ("shift", I), ("accumulate", I), ("act", I), ("alpha", F)]
 
 
+class S2GHead(ctypes.Structure):
+    _fields_ = [("hT", P), ("W", P), ("bias", P), ("labels", P), ("B", I), ("mode", I), ("inv_n", F),
+                ("inv_wsum", F), ("w0", F), ("w1", F)]
+
+
 class S2GReduce(ctypes.Structure):
     _fields_ = [("slabs", P), ("slab", L), ("out", P), ("nslab", I), ("rows", I), ("cols", I)]
 
@@ -46,7 +51,7 @@ SIGNATURES = {
     "s2g_reduce_slabs_multi": [P, I, I, I, F, P],
     "s2g_colsum": [P, L, L, I, P, L, P],
     "s2g_lstm2_fwd": [P, I, I] + [P] * 15,
-    "s2g_lstm2_bwd": [P, I, I] + [P] * 13 + [I, I, P],
+    "s2g_lstm2_bwd": [P, I, I] + [P] * 13 + [I, I, P, P],
     "s2g_lstm2_tangent": [P, I] + [P] * 15,
     "s2g_lstm2_bwd2": [P, I, I] + [P] * 17,
     "s2g_pack_critic": [P] * 9 + [I, P],
