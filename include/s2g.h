@@ -87,6 +87,13 @@ int s2g_reduce_slabs_multi(const S2GReduce* jobs, int njobs, int permute_rows, i
                            void* stream);
 /* part[chunk][c] = sum over a chunk of rows of X[r*ld + c]; nchunk = ceil(rows / rows_per_chunk). */
 int s2g_colsum(const float* X, long ld, long rows, int cols, float* part, long rows_per_chunk, void* stream);
+/* bias gradients of the two LSTM layers (what backward() accumulates into lstm.bias_ih/_hh_l{0,1},
+ * wgan_gp.py:317): column sums of the gate gradients X0 / X1 [rows, 200] (internal gate order), written
+ * (accumulate == 0) or added (1) in torch row order to bias_ih AND bias_hh of each layer (they share one
+ * gradient).  hdotT [B, 50] (optional): its column sum is added to fcw0[50], the penalty's part of
+ * fc.weight[0].  part: scratch of 2 * ceil(rows / 512) * 200 floats.  Two launches. */
+int s2g_bias_sums(const float* X0, const float* X1, long rows, float* part, const float* hdotT, int B,
+                  float* bih0, float* bhh0, float* bih1, float* bhh1, float* fcw0, int accumulate, void* stream);
 
 /* ---- critic LSTM sweeps: nn.LSTM(175, 50, 2, batch_first, dropout) inside
  * Discriminator.forward (wgan_gp.py:189, 217-220) and its autograd.

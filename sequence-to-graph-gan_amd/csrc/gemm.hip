@@ -485,6 +485,70 @@ extern "C" __global__ __launch_bounds__(256) void s2g_k_colsum(const float* __re
                                         red[3][threadIdx.x];
 }
 
+// Bias gradients of both LSTM layers in two launches: the bias of a gate row is the column sum of the
+// gate gradients over all sequence-steps (X0 = layer 0, X1 = layer 1, [rows, 200] each).
+// Pass 1, grid (4, nchunk, 2): partial sums over BIAS_CHUNK rows, four loads in flight per thread.
+#define BIAS_CHUNK 512
+extern "C" __global__ __launch_bounds__(256) void s2g_k_bias_sums_part(const float* __restrict__ X0,
+                                                                       const float* __restrict__ X1, long rows,
+                                                                       float* __restrict__ part) {
+  __shared__ float red[4][64];
+  const float* X = blockIdx.z ? X1 : X0;
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + l;
+  const long r0 = (long)blockIdx.y * BIAS_CHUNK;
+  const long r1 = min(rows, r0 + BIAS_CHUNK);
+  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+  if (c < S2G_G) {
+    long r = r0 + w;
+    for (; r + 12 < r1; r += 16) {
+      s0 += X[r * S2G_G + c]; s1 += X[(r + 4) * S2G_G + c];
+      s2 += X[(r + 8) * S2G_G + c]; s3 += X[(r + 12) * S2G_G + c];
+    }
+    for (; r < r1; r += 4) s0 += X[r * S2G_G + c];
+  }
+  red[w][l] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (w == 0 && c < S2G_G)
+    part[((long)blockIdx.z * gridDim.y + blockIdx.y) * S2G_G + c] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+}
+// Pass 2, grid 8 x 256 threads: block b < 7 owns 64 of the 2 x 200 sums (4 waves split the chunks, fixed
+// order) and writes bias_ih and bias_hh of that layer (the two share one gradient) in torch row order;
+// block 7 adds sum_b hdotT[b][k] to fcw0[k] (the penalty's part of fc.weight[0]) when hdotT is given.
+extern "C" __global__ __launch_bounds__(256) void s2g_k_bias_sums_final(
+    const float* __restrict__ part, int nchunk, const float* __restrict__ hdotT, int B, float* __restrict__ bih0,
+    float* __restrict__ bhh0, float* __restrict__ bih1, float* __restrict__ bhh1, float* __restrict__ fcw0,
+    int accumulate) {
+  __shared__ float red[4][64];
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (blockIdx.x == 7) {
+    if (hdotT == nullptr) return;
+    float s = 0.0f;
+    if (l < S2G_H)
+      for (int b = w; b < B; b += 4) s += hdotT[(long)b * S2G_H + l];
+    red[w][l] = s;
+    __syncthreads();
+    if (w == 0 && l < S2G_H) fcw0[l] += (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+    return;
+  }
+  const int i = blockIdx.x * 64 + l;            // 0 .. 399: layer = i / 200, internal gate row = i % 200
+  const bool ok = i < 2 * S2G_G;
+  const int layer = ok ? i / S2G_G : 0, j = ok ? i % S2G_G : 0;
+  float s = 0.0f;
+  if (ok)
+    for (int z = w; z < nchunk; z += 4) s += part[((long)layer * nchunk + z) * S2G_G + j];
+  red[w][l] = s;
+  __syncthreads();
+  if (w != 0 || !ok) return;
+  s = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+  float* bi = layer ? bih1 : bih0;
+  float* bh = layer ? bhh1 : bhh0;
+  const int o = pt_row(j);
+  const float v = accumulate ? bi[o] + s : s;
+  bi[o] = v;
+  bh[o] = v;
+}
+
 // Tall product C[M,N] = A[M,K] B[K,N] with M = all sequence-steps and K, N <= 224 (the input
 // projection x W_ih0^T, its transpose delta W_ih0 and delta (W_ih0 W_ih0^T)): a block of four waves
 // (one per SIMD) owns 128 rows and ALL N columns, so A is read exactly once and B (<= 160 KB, L2-resident) once per

@@ -98,10 +98,9 @@ __device__ __forceinline__ float row_quads_sum(float v) {
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-// Streaming (non-temporal) global stores for the sweeps' saved activations.  Stores and loads share
-// one in-order completion counter per wave on this ISA, so every wait for a prefetched load also
-// waits for the stores issued before it; the streaming form is acknowledged sooner, which is worth
-// 50 us of a 315 us second-order reverse sweep.  The data is next read by other kernels.
+// Streaming (non-temporal) global stores for rows a sweep saves for OTHER kernels.  Stores and loads
+// share one in-order completion counter per wave on this ISA, so every wait for a prefetched load
+// also waits for the stores issued before it; the streaming form is acknowledged sooner.
 __device__ __forceinline__ void store_stream(float* p, float4 v) {
   __builtin_nontemporal_store((f4){v.x, v.y, v.z, v.w}, reinterpret_cast<f4*>(p));
 }

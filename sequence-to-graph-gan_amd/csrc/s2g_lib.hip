@@ -96,6 +96,17 @@ int s2g_colsum(const float* X, long ld, long rows, int cols, float* part, long r
                      ld, rows, cols, part, rows_per_chunk);
   return LAUNCH_OK();
 }
+int s2g_bias_sums(const float* X0, const float* X1, long rows, float* part, const float* hdotT, int B, float* bih0,
+                  float* bhh0, float* bih1, float* bhh1, float* fcw0, int accumulate, void* stream) {
+  if (!X0 || !X1 || !part || rows <= 0 || !bih0 || !bhh0 || !bih1 || !bhh1) return -1;
+  if (hdotT && (!fcw0 || B <= 0)) return -1;
+  const int nchunk = (int)cdiv(rows, (long)BIAS_CHUNK);
+  hipLaunchKernelGGL(s2g_k_bias_sums_part, dim3(cdiv(S2G_G, 64), nchunk, 2), dim3(256), 0, ST(stream), X0, X1, rows,
+                     part);
+  hipLaunchKernelGGL(s2g_k_bias_sums_final, dim3(8), dim3(256), 0, ST(stream), part, nchunk, hdotT, B, bih0, bhh0,
+                     bih1, bhh1, fcw0, accumulate);
+  return LAUNCH_OK();
+}
 
 int s2g_lstm2_fwd(const S2GSeq* seqs, int nseq, int max_len, const int* tokens, const float* WT0, const float* P,
                   const float* mask, const float* b0, const float* b1, const float* whh0, const float* wih1,

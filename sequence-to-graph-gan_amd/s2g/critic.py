@@ -499,9 +499,15 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         call("s2g_gp_interp", ptr(tokens), ptr(lengths), ptr(fake), ptr(alpha), B, T, Tf, V, ptr(ws["xhat"]), s_)
         _wgrad_launch(eng, built, 0)
 
+    def bias_sums(x0, x1, rows, sc, hdot, accumulate):
+        """column sums of the gate gradients -> lstm.bias_ih / bias_hh of both layers (two launches)"""
+        part = sc.get(2 * ((rows + 511) // 512) * G4)
+        call("s2g_bias_sums", ptr(x0), ptr(x1), rows, ptr(part), ptr(hdot), B, ptr(g["lstm.bias_ih_l0"]),
+             ptr(g["lstm.bias_hh_l0"]), ptr(g["lstm.bias_ih_l1"]), ptr(g["lstm.bias_hh_l1"]), ptr(g["fc.weight"]),
+             int(accumulate), stream_ptr())
+
     def first_order_sums(sc):
-        ops.colsum(d0, n12, G4, G4, g["lstm.bias_ih_l0"], sc, permute_rows=True)
-        ops.colsum(d1, n12, G4, G4, g["lstm.bias_ih_l1"], sc, permute_rows=True)
+        bias_sums(d0, d1, n12, sc, None, False)
 
     drel = ptr(desc, 3 * B * 8)          # group-relative descriptors of the interp third = 4th block of desc
     mrel = ptr(mask, r_int * MASKW) if mask is not None else None
@@ -510,11 +516,7 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
 
     def second_order_sums():
         """bias gradients of the penalty term and its part of fc.weight[0] = sum_b hdot1_final(b)"""
-        ops.colsum(a0, n3, G4, G4, g["lstm.bias_ih_l0"], sc, permute_rows=True, accumulate=True)
-        ops.colsum(a1, n3, G4, G4, g["lstm.bias_ih_l1"], sc, permute_rows=True, accumulate=True)
-        g["lstm.bias_hh_l0"].copy_(g["lstm.bias_ih_l0"])
-        g["lstm.bias_hh_l1"].copy_(g["lstm.bias_ih_l1"])
-        ops.colsum(ws["hdotT"], B, H, H, g["fc.weight"][0], sc, accumulate=True)
+        bias_sums(a0, a1, n3, sc, ws["hdotT"], True)
 
     if side is not None:
         # stream_c: sweep C, sweep D (B workgroups on the reserved quarter of the CUs), then the
@@ -546,17 +548,19 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
             head_losses()
             first_order_sums(sc2)
             join_g.record()
-            if prefetch is not None and eng.stream_g is not None:
-                # the hook's work (not part of the join) follows on this masked stream of its own: started
-                # here it is through before sweep D is (started behind the phase-0 launch it ran into the
-                # iteration's tail: 2 % slower, measured on one box)
-                prefetch()
         with torch.cuda.stream(stream2):
             stream2.wait_event(after_c)
             _wgrad_launch(eng, built, 1)
             join.record()
             if prefetch is not None and eng.stream_g is None:
                 prefetch()          # not part of the join: it may run on beside this iteration's tail
+        if prefetch is not None and eng.stream_g is not None:
+            # The hook's work (not part of the join) goes to the masked stream of its own.  Its light part
+            # starts right away; its heavy, HBM-bound part (the generator's output layer) waits for the
+            # phase-0 and phase-1 products: run side by side the two slow each other down by more than
+            # running them one after the other costs (341 + 289 us against 200 + 83 us).
+            with torch.cuda.stream(eng.stream_g):
+                prefetch(lambda: eng.stream_g.wait_event(join))
         if idle is not None and own:
             with torch.cuda.stream(stream_c):      # free while the sweeps run on the caller's stream
                 stream_c.wait_event(fork)

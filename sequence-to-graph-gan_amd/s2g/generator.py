@@ -84,7 +84,10 @@ class GeneratorEngine:
 
     def forward(self, z: torch.Tensor, labels: torch.Tensor, U: Optional[torch.Tensor], tau: float, hard: bool,
                 training: bool = True, save: bool = True, act: str = "gumbel_softmax",
-                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                out: Optional[torch.Tensor] = None, heavy_after=None) -> torch.Tensor:
+        """heavy_after: optional callable run between the small layers and the output Linear; a caller
+        that runs this forward beside other work makes the current stream wait for an event in it, so
+        that the HBM-bound part (183 MB of weights) does not collide with its own heavy kernels."""
         ops._chk(z, name="noise")
         ops._chk(labels, torch.int64, "labels")
         B = z.shape[0]
@@ -109,6 +112,8 @@ class GeneratorEngine:
         mode = ops.MODES.get(act, 2)
         if mode == 0 and U is None:
             U = torch.rand(B, self.L, self.V, device=dev)      # noise draw only; the sampler is the kernel
+        if heavy_after is not None:
+            heavy_after()
         if self.last_layer_ready is not None:
             # the output Linear's update may still be running on another stream (trainer._generator_step)
             torch.cuda.current_stream().wait_event(self.last_layer_ready)

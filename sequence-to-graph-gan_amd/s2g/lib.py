@@ -50,6 +50,7 @@ SIGNATURES = {
     "s2g_reduce_slabs": [P, L, I, I, I, P, I, I, F, P],
     "s2g_reduce_slabs_multi": [P, I, I, I, F, P],
     "s2g_colsum": [P, L, L, I, P, L, P],
+    "s2g_bias_sums": [P, P, L, P, P, I, P, P, P, P, P, I, P],
     "s2g_lstm2_fwd": [P, I, I] + [P] * 15,
     "s2g_lstm2_bwd": [P, I, I] + [P] * 13 + [I, I, P, P],
     "s2g_lstm2_tangent": [P, I] + [P] * 15,

@@ -146,11 +146,11 @@ class WGANGPTrainer:
             nxt = dict(labels=next_batch["labels"], z=next_batch.get("z"), done=torch.cuda.Event())
             other = self._fake_buf(self._fake_cur ^ 1, B)
 
-            def prefetch():
+            def prefetch(heavy_after=None):
                 if nxt["z"] is None:        # drawn on the prefetch stream: nothing of it sits on the caller's
                     nxt["z"] = torch.randn(B, LATENT, device=dev)
                 self.G.forward(nxt["z"], nxt["labels"], next_batch.get("U"), self.tau, self.hard, training=True,
-                               save=False, out=other)
+                               save=False, out=other, heavy_after=heavy_after)
                 nxt["done"].record()
 
             def idle():

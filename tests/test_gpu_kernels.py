@@ -197,6 +197,39 @@ def test_embed_mul_bwd_matches_torch():
         assert (demb.double().cpu() - want).abs().max() < 1e-4
 
 
+@pytest.mark.parametrize("rows,B", [(32768, 64), (1000, 5), (3, 1)])
+def test_bias_sums_matches_torch(rows, B):
+    """bias_ih = bias_hh gradient = column sums of the gate gradients in torch row order (autograd of the
+    b_ih + b_hh terms of nn.LSTM, wgan_gp.py:189,317), plus the fc.weight[0] part of the penalty."""
+    from s2g.lib import call
+    from s2g.ops import ptr, stream_ptr
+    g = common.gen(50 + B)
+    x0 = torch.randn(rows, 200, generator=g).to(DEV)
+    x1 = torch.randn(rows, 200, generator=g).to(DEV)
+    hd = torch.randn(B, 50, generator=g).to(DEV)
+    part = torch.empty(2 * ((rows + 511) // 512) * 200, device=DEV)
+    perm = torch.tensor([(j & 3) * 50 + (j >> 2) for j in range(200)])
+    base = torch.randn(4, 200, generator=g)
+    fcw = torch.randn(3, 50, generator=g)
+    for accumulate in (0, 1):
+        b = [base[k].clone().to(DEV) for k in range(4)]
+        f = fcw.clone().to(DEV)
+        call("s2g_bias_sums", ptr(x0), ptr(x1), rows, ptr(part), ptr(hd) if accumulate else None, B, ptr(b[0]),
+             ptr(b[1]), ptr(b[2]), ptr(b[3]), ptr(f), accumulate, stream_ptr())
+        torch.cuda.synchronize()
+        for layer, x in enumerate((x0, x1)):
+            want = torch.zeros(200, dtype=torch.float64)
+            want[perm] = x.double().cpu().sum(0)
+            if accumulate:
+                want = want + base[2 * layer].double()
+            assert torch.equal(b[2 * layer], b[2 * layer + 1])
+            assert (b[2 * layer].double().cpu() - want).abs().max() < 1e-3 * max(1.0, want.abs().max().item())
+        want_f = fcw.double().clone()
+        if accumulate:
+            want_f[0] += hd.double().cpu().sum(0)
+        assert (f.double().cpu() - want_f).abs().max() < 1e-4
+
+
 def test_cu_masked_stream_runs_kernels():
     from s2g import lib
     from s2g.lib import call

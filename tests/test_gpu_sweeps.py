@@ -101,6 +101,53 @@ def test_four_sweeps_match_oracle(B, T, ragged, with_mask, scale):
     assert_close(ws["abar0"].cpu().view(B, T, 200), to_internal(A["abar0"]), TOL, "abar0")
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_reverse_sweep_with_inline_head_matches_head_kernels(mode):
+    """s2g_lstm2_bwd(head=...) derives d loss / d h_T per sequence itself: same delta as the sweep fed
+    the d(h_T) of the head + loss kernels (critic batch [real|fake|interp] and generator pass)."""
+    from s2g.critic import CriticEngine, make_desc
+    from s2g.lib import call
+    from s2g.ops import ptr, stream_ptr
+    V, B, T = 175, 4, 19
+    dev = torch.device("cuda:0")
+    nseq = 3 * B if mode == 0 else B
+    SW, p64, x, lengths, _ = setup_case(33, nseq, T, V, True, False, 2.0)
+    eng = CriticEngine(V, dev)
+    eng.load({k: v.float() for k, v in p64.items()})
+    ws = eng.fresh_workspace(nseq, T, 0)
+    P = torch.empty(nseq * T, 200, device=dev)
+    eng.project(x.float().to(dev).contiguous(), P)
+    desc = make_desc([dict(len=int(lengths[b]), p_off=b * T, p_len=T, ca=0.0, cp=1.0, ws_row=b * T, mask_off=-1)
+                      for b in range(nseq)], dev)
+    eng.sweep_fwd(ws, ptr(desc), nseq, T, None, P, None)
+    labels = torch.randint(0, 2, (B,), generator=common.gen(9)).to(dev)
+    inv_n, inv_wsum, cw = 1.0 / B, 1.0 / float((1.0 + labels.float()).sum()), (1.0, 2.0)
+    p, st = eng.params.views, stream_ptr()
+    # reference path: head + loss kernels -> dhT -> sweep
+    if mode == 0:
+        gw, gb = torch.empty(3, 50, device=dev), torch.empty(3, device=dev)
+        call("s2g_critic_head", ptr(ws["hT"]), ptr(p["fc.weight"]), ptr(p["fc.bias"]), ptr(labels), B, inv_n, inv_wsum,
+             cw[0], cw[1], ptr(ws["out"]), ptr(ws["dout"]), ptr(ws["losses"]), ptr(ws["dhT"]), ptr(gw), ptr(gb), st)
+    else:
+        eng.head_fwd(ws, B)
+        call("s2g_generator_loss", ptr(ws["out"]), ptr(labels), B, inv_n, inv_wsum, cw[0], cw[1], ptr(ws["dout"]),
+             ptr(ws["losses"]), st)
+        call("s2g_head_bwd_dh", ptr(ws["dout"]), ptr(p["fc.weight"]), ptr(ws["dhT"]), B, 3, st)
+    eng.sweep_bwd(ws, ptr(desc), nseq, T, None)
+    torch.cuda.synchronize()
+    want0, want1 = ws["delta0"].clone(), ws["delta1"].clone()
+    ws["delta0"].fill_(float("nan")); ws["delta1"].fill_(float("nan")); ws["dhT"].fill_(float("nan"))
+    eng.sweep_bwd(ws, ptr(desc), nseq, T, None, head=eng.head_args(ws, labels, B, mode, inv_n, inv_wsum, cw))
+    torch.cuda.synchronize()
+    assert torch.isfinite(ws["delta0"]).all() and want0.abs().max() > 0
+    assert_close(ws["delta0"].cpu(), want0.cpu().double(), 1e-5, "delta0")
+    assert_close(ws["delta1"].cpu(), want1.cpu().double(), 1e-5, "delta1")
+    # the wrapper rejects a head whose batch layout does not match the launch
+    bad = eng.head_args(ws, labels, B + 1, mode, inv_n, inv_wsum, cw)
+    with pytest.raises(Exception):
+        eng.sweep_bwd(ws, ptr(desc), nseq, T, None, head=bad)
+
+
 def test_token_and_interp_inputs():
     """xproj built in-kernel from tokens (real) and alpha*token + (1-alpha)*projection (interp)."""
     from oracle import wgan_gp_cpu as O
