@@ -272,6 +272,14 @@ class CriticEngine:
              ptr(ws["abar1"]), stream_ptr())
 
 
+def batch_desc(lengths: torch.Tensor, alpha: torch.Tensor, B: int, T: int, Tf: int, use_mask: bool,
+               desc: torch.Tensor) -> None:
+    """Fills the 4B sequence descriptors of a critic batch [real | fake | interp | interp, group-relative]
+    (the padding / packing logic of wgan_gp.py:233-244) on the current stream.  A caller that knows the
+    next batch can do this ahead of time and hand the tensor to critic_iteration(desc=...)."""
+    call("s2g_critic_batch_desc", ptr(lengths), ptr(alpha), B, T, Tf, int(use_mask), ptr(desc), stream_ptr())
+
+
 def make_desc(entries, device) -> torch.Tensor:
     """entries: list of dicts(len, tok_off, p_off, p_len, ca, cp, mask_off, ws_row) -> int32 [n,8]
     tensor with the two floats bit-cast (host-built descriptors for the module-level API/tests)."""
@@ -390,13 +398,15 @@ def _wgrad_grouped(eng: "CriticEngine", jobs, cache_key) -> None:
 
 def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Tensor, labels: torch.Tensor,
                      fake: torch.Tensor, alpha: torch.Tensor, lambda_gp: float, n_global: int, inv_wsum: float,
-                     mask: Optional[torch.Tensor] = None, class_w=(1.0, 2.0), prefetch=None, idle=None):
+                     mask: Optional[torch.Tensor] = None, class_w=(1.0, 2.0), prefetch=None, idle=None,
+                     desc: Optional[torch.Tensor] = None):
     """One critic loss + gradient evaluation (wgan_gp.py:297-317) on the batch
     [real B | fake B | interp B], all three passes sharing each of the four sweeps.
 
     prefetch: optional callable launched on the second stream after this iteration's own work there
     (the trainer generates the next iteration's fake batch in it); it is NOT waited for here, the
     caller synchronises with whatever it enqueued.
+    desc: optional descriptors prepared with batch_desc for exactly these lengths / alpha / T / Tf / mask.
     idle: optional callable run on the caller's stream while it would otherwise wait for the
     second-order sweeps (the trainer draws the next iteration's noise and dropout mask in it).
 
@@ -420,9 +430,12 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         if tuple(mask.shape) != (3 * B * Tw, MASKW):
             raise S2GError("critic_iteration: mask must be [3*B*Tw, 52]")
     p, g, st = eng.params.views, eng.grads.views, stream_ptr()
-    desc = ws["desc"]
+    if desc is None:
+        desc = ws["desc"]
+        batch_desc(lengths, alpha, B, T, Tf, mask is not None, desc)
+    elif desc.dtype != torch.int32 or desc.numel() < 4 * B * 8 or not desc.is_cuda:
+        raise S2GError("critic_iteration: desc must be an int32 device tensor of 4*B descriptors")
     dptr = ptr(desc)
-    call("s2g_critic_batch_desc", ptr(lengths), ptr(alpha), B, T, Tf, int(mask is not None), dptr, st)
     if "Pf" not in ws or ws["Pf"].shape[0] != B * Tf:
         ws["Pf"] = torch.empty(B * Tf, G4, device=eng.device)
         ws["xreal"] = torch.empty(B * T, V, device=eng.device)

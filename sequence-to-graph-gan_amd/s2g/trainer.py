@@ -11,7 +11,7 @@ from typing import Dict, Optional
 import torch
 
 from . import ops
-from .critic import CriticEngine, critic_forward_backward_fake, critic_iteration
+from .critic import CriticEngine, batch_desc, critic_forward_backward_fake, critic_iteration
 from .generator import LATENT, GeneratorEngine, NoComm
 from .lib import S2GError, call
 from .ops import MASKW, H, ptr, stream_ptr
@@ -59,6 +59,8 @@ class WGANGPTrainer:
         self._prefetched = None       # dict(z, labels, done event) of the fake batch the last critic_step prepared
         self._stream = None           # non-blocking stream full_step runs on (see full_step)
         self._g_pending = None        # (done event, tensors kept alive) of a generator update on the side stream
+        self._desc = [None, None]     # descriptor buffers of the batch in flight and of the next one
+        self._desc_cur = 0
         self._g_scratch = ops.Scratch(self.device)
         self.last: Dict[str, torch.Tensor] = {}
 
@@ -118,6 +120,7 @@ class WGANGPTrainer:
         B, T = tokens.shape
         dev = self.device
         n_global = B * self.comm.world
+        desc = None
         pre = self._prefetched
         self._prefetched = None
         if pre is not None and pre["labels"] is labels and (z is None or z is pre["z"]):
@@ -126,6 +129,8 @@ class WGANGPTrainer:
             torch.cuda.current_stream().wait_event(pre["done"])
             if alpha is None:
                 alpha = pre.get("alpha")
+                if pre.get("desc_key") == (B, T, self.L, pre.get("mask") is not None and mask is None):
+                    desc = pre["desc"]
             if mask is None and pre.get("mask") is not None and pre["mask"].shape[0] == 3 * B * max(T, self.L):
                 mask = pre["mask"]
         else:
@@ -159,11 +164,21 @@ class WGANGPTrainer:
                     nxt["alpha"] = torch.rand(B, device=dev)
                 if next_batch.get("mask") is None and self.drop_rate > 0.0 and next_batch.get("T"):
                     nxt["mask"] = dropout_mask(3 * B * max(next_batch["T"], self.L), self.drop_rate, dev)
+                if nxt.get("alpha") is not None and next_batch.get("lengths") is not None and next_batch.get("T"):
+                    # the next batch's sequence descriptors too (two buffers: this batch's are still in use)
+                    self._desc_cur ^= 1
+                    if self._desc[self._desc_cur] is None or self._desc[self._desc_cur].numel() < 4 * B * 8:
+                        self._desc[self._desc_cur] = torch.zeros(4 * B, 8, dtype=torch.int32, device=dev)
+                    use_mask = nxt.get("mask") is not None
+                    batch_desc(next_batch["lengths"], nxt["alpha"].reshape(-1), B, next_batch["T"], self.L, use_mask,
+                               self._desc[self._desc_cur])
+                    nxt["desc"] = self._desc[self._desc_cur]
+                    nxt["desc_key"] = (B, next_batch["T"], self.L, use_mask)
         else:
             idle = None
         losses, pen = critic_iteration(self.D, tokens, lengths, labels, fake, alpha.reshape(-1).contiguous(),
                                        self.lambda_gp, n_global, 1.0 / wsum, mask, CLASS_W, prefetch=prefetch,
-                                       idle=idle)
+                                       idle=idle, desc=desc)
         if prefetch is not None:
             self._prefetched = nxt
             self._fake_cur ^= 1
@@ -269,7 +284,7 @@ class WGANGPTrainer:
                 if i + 1 < n and i % self.n_critic != 0 and batches[i + 1][0].shape[0] == tokens.shape[0]:
                     nn_ = noises[i + 1] if noises is not None else {}
                     nxt = dict(labels=batches[i + 1][1], z=nn_.get("z"), U=nn_.get("U"), alpha=nn_.get("alpha"),
-                               mask=nn_.get("mask"), T=batches[i + 1][0].shape[1])
+                               mask=nn_.get("mask"), T=batches[i + 1][0].shape[1], lengths=batches[i + 1][2])
                 self._critic_step(tokens, labels, lengths, wsum, nz.get("z"), nz.get("U"), nz.get("alpha"),
                                   nz.get("mask"), next_batch=nxt)
                 if i % self.n_critic == 0:
