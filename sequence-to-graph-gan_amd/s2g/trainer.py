@@ -57,6 +57,7 @@ class WGANGPTrainer:
         self._fake = [None, None]     # two persistent fake batches: the one in use and the prefetched next one
         self._fake_cur = 0
         self._prefetched = None       # dict(z, labels, done event) of the fake batch the last critic_step prepared
+        self._gen_prefetched = None   # dict(z, labels, U, fake, done event) of a generator forward made ahead
         self._stream = None           # non-blocking stream full_step runs on (see full_step)
         self._g_pending = None        # (done event, tensors kept alive) of a generator update on the side stream
         self._desc = [None, None]     # descriptor buffers of the batch in flight and of the next one
@@ -110,12 +111,15 @@ class WGANGPTrainer:
     def _critic_step(self, tokens: torch.Tensor, labels: torch.Tensor, lengths: torch.Tensor, wsum: float,
                     z: Optional[torch.Tensor] = None, U: Optional[torch.Tensor] = None,
                     alpha: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
-                    update: bool = True, next_batch=None):
+                    update: bool = True, next_batch=None, gen_next=None):
         """tokens int32 [B,T], labels int64 [B], lengths int32 [B]: device tensors of this rank's shard.
         wsum: global sum of class weights.  Noise defaults to fresh device draws.
         next_batch: optional dict(labels=..., z=..., U=...) of the NEXT critic_step (same batch size,
         generator unchanged in between): its fake batch is generated on the second stream beside this
         step's second-order sweeps and tail, and the next call picks it up.
+        gen_next: optional dict(U=..., mask=...) announcing that generator_step follows with this call's z and
+        labels (wgan_gp.py:323-333): its generator forward depends on the generator only, so it runs beside
+        this step's sweeps as well and generator_step picks it up.
         Returns the loss parts (device tensors; nothing synchronises)."""
         B, T = tokens.shape
         dev = self.device
@@ -174,14 +178,27 @@ class WGANGPTrainer:
                                self._desc[self._desc_cur])
                     nxt["desc"] = self._desc[self._desc_cur]
                     nxt["desc_key"] = (B, next_batch["T"], self.L, use_mask)
+        elif gen_next is not None and self.D.overlap and self.comm.world == 1:
+            gp = dict(z=z, labels=labels, U=gen_next.get("U"), done=torch.cuda.Event())
+
+            def prefetch(heavy_after=None):
+                gp["fake"] = self.G.forward(z, labels, gp["U"], self.tau, self.hard, training=True, save=True,
+                                            heavy_after=heavy_after)
+                gp["done"].record()
+
+            def idle():
+                if gen_next.get("mask") is None and self.drop_rate > 0.0:
+                    gp["mask"] = dropout_mask(B * self.L, self.drop_rate, dev)
         else:
             idle = None
         losses, pen = critic_iteration(self.D, tokens, lengths, labels, fake, alpha.reshape(-1).contiguous(),
                                        self.lambda_gp, n_global, 1.0 / wsum, mask, CLASS_W, prefetch=prefetch,
                                        idle=idle, desc=desc)
-        if prefetch is not None:
+        if prefetch is not None and next_batch is not None:
             self._prefetched = nxt
             self._fake_cur ^= 1
+        elif prefetch is not None:
+            self._gen_prefetched = gp
         if update:
             self.tD += 1
             self._adam(self.D, self.mD, self.vD, self.tD)
@@ -210,7 +227,15 @@ class WGANGPTrainer:
             self._prefetched = None
         B = z.shape[0]
         n_global = B * self.comm.world
-        fake = self.G.forward(z, labels, U, self.tau, self.hard, training=True, save=True)
+        gp, self._gen_prefetched = self._gen_prefetched, None
+        if gp is not None:
+            torch.cuda.current_stream().wait_event(gp["done"])
+        if gp is not None and gp["z"] is z and gp["labels"] is labels and gp["U"] is U and "fake" in gp:
+            fake = gp["fake"]                     # forward (and its saved activations) made beside the critic step
+            if mask is None:
+                mask = gp.get("mask")
+        else:
+            fake = self.G.forward(z, labels, U, self.tau, self.hard, training=True, save=True)
         if mask is None and self.drop_rate > 0.0:
             mask = dropout_mask(B * self.L, self.drop_rate, self.device)
         losses, dfake = critic_forward_backward_fake(self.D, fake, labels, n_global, 1.0 / wsum, mask, CLASS_W)
@@ -285,8 +310,9 @@ class WGANGPTrainer:
                     nn_ = noises[i + 1] if noises is not None else {}
                     nxt = dict(labels=batches[i + 1][1], z=nn_.get("z"), U=nn_.get("U"), alpha=nn_.get("alpha"),
                                mask=nn_.get("mask"), T=batches[i + 1][0].shape[1], lengths=batches[i + 1][2])
+                gen = dict(U=nz.get("U2"), mask=nz.get("mask_g")) if i % self.n_critic == 0 else None
                 self._critic_step(tokens, labels, lengths, wsum, nz.get("z"), nz.get("U"), nz.get("alpha"),
-                                  nz.get("mask"), next_batch=nxt)
+                                  nz.get("mask"), next_batch=nxt, gen_next=gen)
                 if i % self.n_critic == 0:
                     self._generator_step(U=nz.get("U2"), mask=nz.get("mask_g"), defer_join=i + 1 < n)
             self._join_generator()
