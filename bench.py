@@ -111,7 +111,9 @@ def main():
 
     def one_step(k):
         batches = [pool[(k * N_CRITIC + i) % len(pool)][:4] for i in range(N_CRITIC)]
-        tr.full_step(batches)
+        # the loader peeks one batch ahead: the next step's first fake batch does not depend on this step's
+        # remaining updates of the critic, and the generator stays fixed until that batch's critic update
+        tr.full_step(batches, lookahead=pool[((k + 1) * N_CRITIC) % len(pool)][:4])
 
     # The step runs on a non-blocking stream of its own: the CU-masked second stream of the critic is a
     # blocking stream, i.e. it would synchronise implicitly with every launch on the NULL stream.

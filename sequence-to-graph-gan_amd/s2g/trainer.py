@@ -292,7 +292,7 @@ class WGANGPTrainer:
         return t[0]
 
     # ------------------------------------------------------------------ the full step
-    def full_step(self, batches, noises=None):
+    def full_step(self, batches, noises=None, lookahead=None, lookahead_noise=None):
         """batches: n_critic device batches (tokens i32, labels i64, lengths i32, wsum).  Generator
         update after the first batch's critic update (i % n_critic == 0, wgan_gp.py:323).
 
@@ -300,16 +300,20 @@ class WGANGPTrainer:
         return): the critic's CU-masked second stream is a blocking stream and would otherwise
         synchronise with every launch when the caller sits on the NULL stream.  While the generator
         stays fixed (between two generator updates) the next batch's fake sequences are prefetched
-        beside the current batch's second-order sweeps."""
+        beside the current batch's second-order sweeps.
+        lookahead: the batch the NEXT call starts with, if the caller's loader can peek (the generator
+        does not change between this call's last batch and that one, so its fake sequences are
+        prefetched too); lookahead_noise: its injected noise dict, as in `noises`."""
         with self._own_stream():
             n = len(batches)
             for i, (tokens, labels, lengths, wsum) in enumerate(batches):
                 nz = noises[i] if noises is not None else {}
                 nxt = None
-                if i + 1 < n and i % self.n_critic != 0 and batches[i + 1][0].shape[0] == tokens.shape[0]:
-                    nn_ = noises[i + 1] if noises is not None else {}
-                    nxt = dict(labels=batches[i + 1][1], z=nn_.get("z"), U=nn_.get("U"), alpha=nn_.get("alpha"),
-                               mask=nn_.get("mask"), T=batches[i + 1][0].shape[1], lengths=batches[i + 1][2])
+                nb = batches[i + 1] if i + 1 < n else lookahead
+                if nb is not None and i % self.n_critic != 0 and nb[0].shape[0] == tokens.shape[0]:
+                    nn_ = (noises[i + 1] if noises is not None else {}) if i + 1 < n else (lookahead_noise or {})
+                    nxt = dict(labels=nb[1], z=nn_.get("z"), U=nn_.get("U"), alpha=nn_.get("alpha"),
+                               mask=nn_.get("mask"), T=nb[0].shape[1], lengths=nb[2])
                 gen = dict(U=nz.get("U2"), mask=nz.get("mask_g")) if i % self.n_critic == 0 else None
                 self._critic_step(tokens, labels, lengths, wsum, nz.get("z"), nz.get("U"), nz.get("alpha"),
                                   nz.get("mask"), next_batch=nxt, gen_next=gen)
