@@ -125,7 +125,7 @@ int s2g_lstm2_bwd(const S2GSeq* seqs, int nseq, int rows_per_seq, const float* m
                   const float* wih1, const float* whh1, const float* gates0, const float* cell0,
                   const float* gates1, const float* cell1, const float* dhT, float* delta0, float* delta1,
                   float* adj0, float* adj1, int adj_seq0, int adj_row0, const struct S2GHead* head,
-                  void* stream);
+                  float* bsum, void* stream);
 /* tangent (forward-mode) sweep along an input direction whose projection is Xdot [rows, 200];
  * with s2g_lstm2_bwd2 it replaces the double backward that create_graph=True makes autograd
  * run for the gradient penalty (wgan_gp.py:251, 256, 317). */
@@ -137,7 +137,13 @@ int s2g_lstm2_bwd2(const S2GSeq* seqs, int nseq, int rows_per_seq, const float* 
                    const float* wih1, const float* whh1, const float* gates0, const float* cell0,
                    const float* gates1, const float* cell1, const float* adot0, const float* celld0,
                    const float* adot1, const float* celld1, const float* adj0, const float* adj1,
-                   float* abar0, float* abar1, void* stream);
+                   float* abar0, float* abar1, float* bsum, void* stream);
+/* bsum (optional, both reverse sweeps): [2][nseq][200]; sequence n's sums over time of its layer-0
+ * (bsum[0][n]) and layer-1 (bsum[1][n]) gate gradients, i.e. its share of the bias gradients, left
+ * behind by the sweep at no extra pass over memory.  s2g_bias_sums_final adds up the first nseq rows
+ * of each layer (layers layer_stride floats apart) into bias_ih / bias_hh as s2g_bias_sums does. */
+int s2g_bias_sums_final(const float* sums, int nseq, long layer_stride, const float* hdotT, int B, float* bih0,
+                        float* bhh0, float* bih1, float* bhh1, float* fcw0, int accumulate, void* stream);
 
 /* permuted copies of lstm.weight_ih_l0 and the summed biases (Discriminator parameters,
  * wgan_gp.py:189): WT0 [V,200], W0p [200, roundup(V,4)] (pad columns must

@@ -512,11 +512,12 @@ extern "C" __global__ __launch_bounds__(256) void s2g_k_bias_sums_part(const flo
   if (w == 0 && c < S2G_G)
     part[((long)blockIdx.z * gridDim.y + blockIdx.y) * S2G_G + c] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
 }
-// Pass 2, grid 8 x 256 threads: block b < 7 owns 64 of the 2 x 200 sums (4 waves split the chunks, fixed
-// order) and writes bias_ih and bias_hh of that layer (the two share one gradient) in torch row order;
+// Pass 2, grid 8 x 256 threads: block b < 7 owns 64 of the 2 x 200 sums (4 waves split the nchunk partial
+// rows of a layer, which start layer_stride floats apart; fixed order) and writes bias_ih and bias_hh of that layer (the two share one gradient) in torch row order;
 // block 7 adds sum_b hdotT[b][k] to fcw0[k] (the penalty's part of fc.weight[0]) when hdotT is given.
 extern "C" __global__ __launch_bounds__(256) void s2g_k_bias_sums_final(
-    const float* __restrict__ part, int nchunk, const float* __restrict__ hdotT, int B, float* __restrict__ bih0,
+    const float* __restrict__ part, int nchunk, long layer_stride, const float* __restrict__ hdotT, int B,
+    float* __restrict__ bih0,
     float* __restrict__ bhh0, float* __restrict__ bih1, float* __restrict__ bhh1, float* __restrict__ fcw0,
     int accumulate) {
   __shared__ float red[4][64];
@@ -536,7 +537,7 @@ extern "C" __global__ __launch_bounds__(256) void s2g_k_bias_sums_final(
   const int layer = ok ? i / S2G_G : 0, j = ok ? i % S2G_G : 0;
   float s = 0.0f;
   if (ok)
-    for (int z = w; z < nchunk; z += 4) s += part[((long)layer * nchunk + z) * S2G_G + j];
+    for (int z = w; z < nchunk; z += 4) s += part[layer * layer_stride + (long)z * S2G_G + j];
   red[w][l] = s;
   __syncthreads();
   if (w != 0 || !ok) return;

@@ -116,11 +116,14 @@ __device__ __forceinline__ void zero_tail(float* buf, int ws_row, int len, int T
 // a cell wave would sit in front of every wait for its prefetched activations: measured, the
 // 16-byte store per step cost the second-order sweep a quarter of its time.  Here 50 lanes write
 // one full 800-byte row per step.
+// sum1/sum0 (optional): the same lanes also add up the gate gradients over the sequence's steps and
+// leave the 200 sums of layer 1 / layer 0 there (this sequence's share of the bias gradients, which
+// would otherwise cost a pass over all saved gate gradients).
 template <bool STORES>
 __device__ __forceinline__ void reverse_projection(const S2GSeq& sq, const float* mask, const float* wih1,
                                                    const float* dummy, const float* d1buf, const float* d0buf,
-                                                   float* dybuf, float* out1, float* out0, int wv, int lane,
-                                                   int nit) {
+                                                   float* dybuf, float* out1, float* out0, float* sum1,
+                                                   float* sum0, int wv, int lane, int nit) {
   const int len = sq.len;
   const bool has_mask = sq.mask_off >= 0 && mask != nullptr;
   const int p = 8 * (wv - 4) + (lane >> 3), s = lane & 7;
@@ -133,7 +136,10 @@ __device__ __forceinline__ void reverse_projection(const S2GSeq& sq, const float
   const int sm = has_mask ? S2G_MASKW : 0;
   // store duty: wave 6 -> layer 1 (its cell waves handled t = len-i one iteration ago), wave 7 ->
   // layer 0 (t = len+2-i); lane = unit
+  const bool summer = sum1 != nullptr && wv >= 6 && lane < S2G_H;
   const bool storer = STORES && wv >= 6 && lane < S2G_H;
+  const bool reader = storer || summer;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   const int su = lane < S2G_H ? lane : 0;
   const float* sbuf = (wv == 6) ? d1buf : d0buf;
   float* sout = ((wv == 6) ? out1 : out0) + 4 * su;
@@ -151,10 +157,12 @@ __device__ __forceinline__ void reverse_projection(const S2GSeq& sq, const float
         const int t = len - i;
         const int ts = t + slag;
         float4 dv;
-        const bool st = storer && ts >= 0 && ts < len;
-        if (st) {
+        const bool rd = reader && ts >= 0 && ts < len;
+        const bool st = STORES && rd;
+        if (rd) {
           const float* b = sbuf + (ts & 1) * DVEC;
           dv = make_float4(b[q0], b[q1], b[q2], b[q3]);
+          acc.x += dv.x; acc.y += dv.y; acc.z += dv.z; acc.w += dv.w;
         }
         if (t >= 0 && t < len) {
           const float dy = matvecT_pair(w, d1buf + (t & 1) * DVEC + 28 * s);
@@ -167,10 +175,13 @@ __device__ __forceinline__ void reverse_projection(const S2GSeq& sq, const float
     }
   }
   // layer 0's last step (t = 0) was published in the last iteration
-  if (STORES && wv == 7 && lane < S2G_H && len >= 1) {
+  if (reader && wv == 7 && len >= 1) {
     const float* b = d0buf;
-    store_stream(sout, make_float4(b[q0], b[q1], b[q2], b[q3]));
+    const float4 dv = make_float4(b[q0], b[q1], b[q2], b[q3]);
+    acc.x += dv.x; acc.y += dv.y; acc.z += dv.z; acc.w += dv.w;
+    if (STORES) store_stream(sout, dv);
   }
+  if (summer) *reinterpret_cast<float4*>(((wv == 6) ? sum1 : sum0) + 4 * su) = acc;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -184,7 +195,8 @@ extern "C" __global__ __launch_bounds__(BWD_THREADS) void s2g_k_lstm2_bwd(
     const float* __restrict__ wih1, const float* __restrict__ whh1, const float* __restrict__ gates0,
     const float* __restrict__ cell0, const float* __restrict__ gates1, const float* __restrict__ cell1,
     const float* __restrict__ dhT, float* __restrict__ delta0, float* __restrict__ delta1,
-    float* __restrict__ adj0, float* __restrict__ adj1, int T, int adj_seq0, int adj_row0, S2GHead head) {
+    float* __restrict__ adj0, float* __restrict__ adj1, int T, int adj_seq0, int adj_row0, S2GHead head,
+    float* __restrict__ bsum) {
   __shared__ __attribute__((aligned(16))) float lds[4 * DVEC + 128];
   float* d1buf = lds;                // delta of layer 1 [2][DVEC]
   float* d0buf = lds + 2 * DVEC;     // delta of layer 0 [2][DVEC]
@@ -197,16 +209,20 @@ extern "C" __global__ __launch_bounds__(BWD_THREADS) void s2g_k_lstm2_bwd(
   const int lane = tid & 63;
   const int len = sq.len;
 
+  // bsum (optional) [2][gridDim.x][200]: per-sequence sums over time of delta0 / delta1
+  float* bs0 = bsum ? bsum + (size_t)n * S2G_G : nullptr;
+  float* bs1 = bsum ? bsum + ((size_t)gridDim.x + n) * S2G_G : nullptr;
   if (len <= 0) {
     zero_tail(delta0, sq.ws_row, 0, T, S2G_G);
     zero_tail(delta1, sq.ws_row, 0, T, S2G_G);
+    if (bsum && tid < S2G_G) { bs0[tid] = 0.0f; bs1[tid] = 0.0f; }
     return;
   }
   for (int i = tid; i < 4 * DVEC + 128; i += BWD_THREADS) lds[i] = 0.0f;
   const int nit = len + 2;
 
   if (wv >= 4) {
-    reverse_projection<false>(sq, mask, wih1, whh0, d1buf, d0buf, dybuf, nullptr, nullptr, wv, lane, nit);
+    reverse_projection<false>(sq, mask, wih1, whh0, d1buf, d0buf, dybuf, nullptr, nullptr, bs1, bs0, wv, lane, nit);
   } else {
     // ---------------- cell waves: 0,1 = layer 1 (lag 0), 2,3 = layer 0 (lag 2) ----------------
     const bool top = wv < 2;
@@ -320,7 +336,7 @@ extern "C" __global__ __launch_bounds__(BWD_THREADS) void s2g_k_lstm2_bwd2(
     const float* __restrict__ cell0, const float* __restrict__ gates1, const float* __restrict__ cell1,
     const float* __restrict__ adot0, const float* __restrict__ celld0, const float* __restrict__ adot1,
     const float* __restrict__ celld1, const float* __restrict__ adj0, const float* __restrict__ adj1,
-    float* __restrict__ abar0, float* __restrict__ abar1, int T) {
+    float* __restrict__ abar0, float* __restrict__ abar1, int T, float* __restrict__ bsum) {
   __shared__ __attribute__((aligned(16))) float lds[4 * DVEC + 128];
   float* d1buf = lds;
   float* d0buf = lds + 2 * DVEC;
@@ -333,9 +349,12 @@ extern "C" __global__ __launch_bounds__(BWD_THREADS) void s2g_k_lstm2_bwd2(
   const int lane = tid & 63;
   const int len = sq.len;
 
+  float* bs0 = bsum ? bsum + (size_t)n * S2G_G : nullptr;       // as in sweep B: sums over time of abar0 / abar1
+  float* bs1 = bsum ? bsum + ((size_t)gridDim.x + n) * S2G_G : nullptr;
   if (len <= 0) {
     zero_tail(abar0, sq.ws_row, 0, T, S2G_G);
     zero_tail(abar1, sq.ws_row, 0, T, S2G_G);
+    if (bsum && tid < S2G_G) { bs0[tid] = 0.0f; bs1[tid] = 0.0f; }
     return;
   }
   for (int i = tid; i < 4 * DVEC + 128; i += BWD_THREADS) lds[i] = 0.0f;
@@ -343,7 +362,8 @@ extern "C" __global__ __launch_bounds__(BWD_THREADS) void s2g_k_lstm2_bwd2(
 
   if (wv >= 4) {
     const size_t rb = (size_t)sq.ws_row * S2G_G;
-    reverse_projection<true>(sq, mask, wih1, whh0, d1buf, d0buf, dybuf, abar1 + rb, abar0 + rb, wv, lane, nit);
+    reverse_projection<true>(sq, mask, wih1, whh0, d1buf, d0buf, dybuf, abar1 + rb, abar0 + rb, bs1, bs0, wv, lane,
+                             nit);
   } else {
     const bool top = wv < 2;
     const int lag = top ? 0 : 2;

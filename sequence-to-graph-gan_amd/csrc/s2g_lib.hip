@@ -103,8 +103,16 @@ int s2g_bias_sums(const float* X0, const float* X1, long rows, float* part, cons
   const int nchunk = (int)cdiv(rows, (long)BIAS_CHUNK);
   hipLaunchKernelGGL(s2g_k_bias_sums_part, dim3(cdiv(S2G_G, 64), nchunk, 2), dim3(256), 0, ST(stream), X0, X1, rows,
                      part);
-  hipLaunchKernelGGL(s2g_k_bias_sums_final, dim3(8), dim3(256), 0, ST(stream), part, nchunk, hdotT, B, bih0, bhh0,
-                     bih1, bhh1, fcw0, accumulate);
+  hipLaunchKernelGGL(s2g_k_bias_sums_final, dim3(8), dim3(256), 0, ST(stream), part, nchunk, (long)nchunk * S2G_G,
+                     hdotT, B, bih0, bhh0, bih1, bhh1, fcw0, accumulate);
+  return LAUNCH_OK();
+}
+int s2g_bias_sums_final(const float* sums, int nseq, long layer_stride, const float* hdotT, int B, float* bih0,
+                        float* bhh0, float* bih1, float* bhh1, float* fcw0, int accumulate, void* stream) {
+  if (!sums || nseq <= 0 || layer_stride < (long)nseq * S2G_G || !bih0 || !bhh0 || !bih1 || !bhh1) return -1;
+  if (hdotT && (!fcw0 || B <= 0)) return -1;
+  hipLaunchKernelGGL(s2g_k_bias_sums_final, dim3(8), dim3(256), 0, ST(stream), sums, nseq, layer_stride, hdotT, B,
+                     bih0, bhh0, bih1, bhh1, fcw0, accumulate);
   return LAUNCH_OK();
 }
 
@@ -123,7 +131,8 @@ int s2g_lstm2_fwd(const S2GSeq* seqs, int nseq, int max_len, const int* tokens, 
 int s2g_lstm2_bwd(const S2GSeq* seqs, int nseq, int rows_per_seq, const float* mask, const float* whh0,
                   const float* wih1, const float* whh1, const float* gates0, const float* cell0,
                   const float* gates1, const float* cell1, const float* dhT, float* delta0, float* delta1,
-                  float* adj0, float* adj1, int adj_seq0, int adj_row0, const S2GHead* head, void* stream) {
+                  float* adj0, float* adj1, int adj_seq0, int adj_row0, const S2GHead* head, float* bsum,
+                  void* stream) {
   if (!seqs || nseq <= 0 || rows_per_seq <= 0) return -1;
   if (!whh0 || !wih1 || !whh1 || !gates0 || !cell0 || !gates1 || !cell1 || !delta0 || !delta1) return -1;
   if ((adj0 == nullptr) != (adj1 == nullptr)) return -1;
@@ -137,7 +146,7 @@ int s2g_lstm2_bwd(const S2GSeq* seqs, int nseq, int rows_per_seq, const float* m
     return -1;
   }
   hipLaunchKernelGGL(s2g_k_lstm2_bwd, dim3(nseq), dim3(BWD_THREADS), 0, ST(stream), seqs, mask, whh0, wih1, whh1, gates0,
-                     cell0, gates1, cell1, dhT, delta0, delta1, adj0, adj1, rows_per_seq, adj_seq0, adj_row0, h);
+                     cell0, gates1, cell1, dhT, delta0, delta1, adj0, adj1, rows_per_seq, adj_seq0, adj_row0, h, bsum);
   return LAUNCH_OK();
 }
 
@@ -157,12 +166,12 @@ int s2g_lstm2_bwd2(const S2GSeq* seqs, int nseq, int rows_per_seq, const float* 
                    const float* wih1, const float* whh1, const float* gates0, const float* cell0,
                    const float* gates1, const float* cell1, const float* adot0, const float* celld0,
                    const float* adot1, const float* celld1, const float* adj0, const float* adj1, float* abar0,
-                   float* abar1, void* stream) {
+                   float* abar1, float* bsum, void* stream) {
   if (!seqs || nseq <= 0 || rows_per_seq <= 0) return -1;
   if (!whh0 || !wih1 || !whh1 || !gates0 || !cell0 || !gates1 || !cell1) return -1;
   if (!adot0 || !celld0 || !adot1 || !celld1 || !adj0 || !adj1 || !abar0 || !abar1) return -1;
   hipLaunchKernelGGL(s2g_k_lstm2_bwd2, dim3(nseq), dim3(BWD_THREADS), 0, ST(stream), seqs, mask, whh0, wih1, whh1, gates0,
-                     cell0, gates1, cell1, adot0, celld0, adot1, celld1, adj0, adj1, abar0, abar1, rows_per_seq);
+                     cell0, gates1, cell1, adot0, celld0, adot1, celld1, adj0, adj1, abar0, abar1, rows_per_seq, bsum);
   return LAUNCH_OK();
 }
 

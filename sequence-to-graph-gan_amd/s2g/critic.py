@@ -138,7 +138,7 @@ class CriticEngine:
             ws.update(adj0=z(so_rows, 2 * H), adj1=z(so_rows, 2 * H), adot0=z(so_rows, G4), adot1=z(so_rows, G4),
                       celld0=z(so_rows, G4), celld1=z(so_rows, G4), abar0=z(so_rows, G4), abar1=z(so_rows, G4),
                       hdotT=z(so_seqs, H), G=z(so_rows, self.V), Pv=z(so_rows, G4), pen=z(so_seqs),
-                      norms=z(so_seqs))
+                      norms=z(so_seqs), bsumB=z(2, nseq, G4), bsumD=z(2, so_seqs, G4))
         return ws
 
     def workspace_g(self, B: int, Tf: int) -> Dict[str, torch.Tensor]:
@@ -243,16 +243,19 @@ class CriticEngine:
         return S2GHead(ptr(ws["hT"]), ptr(p["fc.weight"]), ptr(p["fc.bias"]), ptr(labels), B, mode, inv_n, inv_wsum,
                        class_w[0], class_w[1])
 
-    def sweep_bwd(self, ws, desc_ptr, nseq, Tw, mask, adj_seq0: int = -1, head: Optional[S2GHead] = None) -> None:
+    def sweep_bwd(self, ws, desc_ptr, nseq, Tw, mask, adj_seq0: int = -1, head: Optional[S2GHead] = None,
+                  bsum: Optional[torch.Tensor] = None) -> None:
         """adj_seq0 >= 0: sequences [adj_seq0, nseq) also store (dh, dc) into the compact adj0/adj1
         buffers (their row 0 = first workspace row of sequence adj_seq0).
-        head: the sweep derives d loss / d h_T itself from ws["hT"] (head_args) instead of reading ws["dhT"]."""
+        head: the sweep derives d loss / d h_T itself from ws["hT"] (head_args) instead of reading ws["dhT"].
+        bsum [2, nseq, 200]: receives every sequence's sums over time of delta0 / delta1."""
         whh0, wih1, whh1 = self._w()
         store = adj_seq0 >= 0
         call("s2g_lstm2_bwd", desc_ptr, nseq, Tw, ptr(mask), whh0, wih1, whh1, ptr(ws["gates0"]), ptr(ws["cell0"]),
              ptr(ws["gates1"]), ptr(ws["cell1"]), ptr(ws["dhT"]), ptr(ws["delta0"]), ptr(ws["delta1"]),
              ptr(ws["adj0"]) if store else None, ptr(ws["adj1"]) if store else None,
-             max(adj_seq0, 0), max(adj_seq0, 0) * Tw, ctypes.byref(head) if head is not None else None, stream_ptr())
+             max(adj_seq0, 0), max(adj_seq0, 0) * Tw, ctypes.byref(head) if head is not None else None,
+             ptr(bsum), stream_ptr())
 
     def sweep_tangent(self, ws, desc_ptr, nseq, mask_ptr, row0: int) -> None:
         """Sequences of `desc` count rows from workspace row `row0` (their descriptors are relative)."""
@@ -263,13 +266,14 @@ class CriticEngine:
              ptr(ws["adot0"]), ptr(ws["celld0"]), ptr(ws["adot1"]), ptr(ws["celld1"]), ptr(ws["hdotT"]),
              stream_ptr())
 
-    def sweep_bwd2(self, ws, desc_ptr, nseq, Tw, mask_ptr, row0: int) -> None:
+    def sweep_bwd2(self, ws, desc_ptr, nseq, Tw, mask_ptr, row0: int, bsum: Optional[torch.Tensor] = None) -> None:
+        """bsum [2, nseq, 200]: receives every sequence's sums over time of abar0 / abar1."""
         whh0, wih1, whh1 = self._w()
         o = row0 * G4
         call("s2g_lstm2_bwd2", desc_ptr, nseq, Tw, mask_ptr, whh0, wih1, whh1, ptr(ws["gates0"], o),
              ptr(ws["cell0"], o), ptr(ws["gates1"], o), ptr(ws["cell1"], o), ptr(ws["adot0"]), ptr(ws["celld0"]),
              ptr(ws["adot1"]), ptr(ws["celld1"]), ptr(ws["adj0"]), ptr(ws["adj1"]), ptr(ws["abar0"]),
-             ptr(ws["abar1"]), stream_ptr())
+             ptr(ws["abar1"]), ptr(bsum), stream_ptr())
 
 
 def batch_desc(lengths: torch.Tensor, alpha: torch.Tensor, B: int, T: int, Tf: int, use_mask: bool,
@@ -464,7 +468,8 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
 
     # sweep B on 3B sequences (the interp third with d(out) = e0 and stored adjoints)
     head = eng.head_args(ws, labels, B, 0, inv_n, inv_wsum, class_w)
-    eng.timed("s2g_k_lstm2_bwd", lambda: eng.sweep_bwd(ws, dptr, 3 * B, Tw, mask, adj_seq0=2 * B, head=head))
+    eng.timed("s2g_k_lstm2_bwd", lambda: eng.sweep_bwd(ws, dptr, 3 * B, Tw, mask, adj_seq0=2 * B, head=head,
+                                                       bsum=ws["bsumB"]))
     # Penalty of the interp third (wgan_gp.py:247-256).  With g_t = W_ih0^T delta0_t the norm is
     # |g_b|^2 = sum_t delta0_t . (M2 delta0_t), M2 = W_ih0 W_ih0^T, and the projected direction the
     # tangent sweep consumes is coef_b * M2 delta0_t: one 200x200 product on the critical path.  The
@@ -512,15 +517,15 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         call("s2g_gp_interp", ptr(tokens), ptr(lengths), ptr(fake), ptr(alpha), B, T, Tf, V, ptr(ws["xhat"]), s_)
         _wgrad_launch(eng, built, 0)
 
-    def bias_sums(x0, x1, rows, sc, hdot, accumulate):
-        """column sums of the gate gradients -> lstm.bias_ih / bias_hh of both layers (two launches)"""
-        part = sc.get(2 * ((rows + 511) // 512) * G4)
-        call("s2g_bias_sums", ptr(x0), ptr(x1), rows, ptr(part), ptr(hdot), B, ptr(g["lstm.bias_ih_l0"]),
+    def bias_sums(sums, nseq, hdot, accumulate):
+        """bias gradients of both layers from the per-sequence sums the reverse sweeps leave behind
+        (sequences [0, nseq) of sums [2, *, 200]); one small launch"""
+        call("s2g_bias_sums_final", ptr(sums), nseq, sums.shape[1] * G4, ptr(hdot), B, ptr(g["lstm.bias_ih_l0"]),
              ptr(g["lstm.bias_hh_l0"]), ptr(g["lstm.bias_ih_l1"]), ptr(g["lstm.bias_hh_l1"]), ptr(g["fc.weight"]),
              int(accumulate), stream_ptr())
 
     def first_order_sums(sc):
-        bias_sums(d0, d1, n12, sc, None, False)
+        bias_sums(ws["bsumB"], 2 * B, None, False)         # real + fake sequences; the interp third only seeds the penalty
 
     drel = ptr(desc, 3 * B * 8)          # group-relative descriptors of the interp third = 4th block of desc
     mrel = ptr(mask, r_int * MASKW) if mask is not None else None
@@ -529,7 +534,7 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
 
     def second_order_sums():
         """bias gradients of the penalty term and its part of fc.weight[0] = sum_b hdot1_final(b)"""
-        bias_sums(a0, a1, n3, sc, ws["hdotT"], True)
+        bias_sums(ws["bsumD"], B, ws["hdotT"], True)
 
     if side is not None:
         # stream_c: sweep C, sweep D (B workgroups on the reserved quarter of the CUs), then the
@@ -580,7 +585,7 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
                 idle()
         with torch.cuda.stream(sweeps):
             after_d = torch.cuda.Event()
-            eng.timed("s2g_k_lstm2_bwd2", lambda: eng.sweep_bwd2(ws, drel, B, Tw, mrel, r_int))
+            eng.timed("s2g_k_lstm2_bwd2", lambda: eng.sweep_bwd2(ws, drel, B, Tw, mrel, r_int, bsum=ws["bsumD"]))
             after_d.record()
         if idle is not None and not own:
             idle()
@@ -599,7 +604,7 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         cur.wait_event(join_c)
     else:
         eng.timed("s2g_k_lstm2_tangent", lambda: eng.sweep_tangent(ws, drel, B, mrel, r_int))
-        eng.timed("s2g_k_lstm2_bwd2", lambda: eng.sweep_bwd2(ws, drel, B, Tw, mrel, r_int))
+        eng.timed("s2g_k_lstm2_bwd2", lambda: eng.sweep_bwd2(ws, drel, B, Tw, mrel, r_int, bsum=ws["bsumD"]))
         head_losses()
         first_order(sc)
         first_order_sums(sc)

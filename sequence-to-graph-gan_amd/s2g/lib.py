@@ -51,10 +51,11 @@ SIGNATURES = {
     "s2g_reduce_slabs_multi": [P, I, I, I, F, P],
     "s2g_colsum": [P, L, L, I, P, L, P],
     "s2g_bias_sums": [P, P, L, P, P, I, P, P, P, P, P, I, P],
+    "s2g_bias_sums_final": [P, I, L, P, I, P, P, P, P, P, I, P],
     "s2g_lstm2_fwd": [P, I, I] + [P] * 15,
-    "s2g_lstm2_bwd": [P, I, I] + [P] * 13 + [I, I, P, P],
+    "s2g_lstm2_bwd": [P, I, I] + [P] * 13 + [I, I, P, P, P],
     "s2g_lstm2_tangent": [P, I] + [P] * 15,
-    "s2g_lstm2_bwd2": [P, I, I] + [P] * 17,
+    "s2g_lstm2_bwd2": [P, I, I] + [P] * 18,
     "s2g_pack_critic": [P] * 9 + [I, P],
     "s2g_critic_batch_desc": [P, P, I, I, I, I, P, P],
     "s2g_head_fwd": [P, P, P, P, I, I, P],
