@@ -86,15 +86,34 @@ def main():
     lib.get()                                    # fail loudly if libs2g.so is missing
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
-    comm, rank, local, world = init_from_env("nccl")
+    # S2G_REHEARSE=1: every rank on GPU 0 with the gloo backend -- exercises the multi-rank code path
+    # on a one-GPU machine (its number is meaningless; RCCL needs one GPU per rank)
+    rehearse = os.environ.get("S2G_REHEARSE") == "1"
+    comm, rank, local, world = init_from_env("gloo" if rehearse else "nccl")
     if world != max(a.gpus, 1):
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run")
+    if rehearse:
+        local = 0
+        if os.environ.get("S2G_TRACE_COMM") == "1" and comm is not None:
+            inner, count = comm.allreduce, [0]
+
+            def traced(t):
+                count[0] += 1
+                print(f"[rank {rank}] allreduce #{count[0]} numel={t.numel()} stream={torch.cuda.current_stream().cuda_stream:#x}: "
+                      "waiting for the GPU", flush=True)
+                torch.cuda.synchronize()
+                print(f"[rank {rank}] allreduce #{count[0]}: GPU idle, reducing", flush=True)
+                inner(t)
+                print(f"[rank {rank}] allreduce #{count[0]} done", flush=True)
+            comm.allreduce = traced
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
     import common
     tr = WGANGPTrainer(V, GEN_SEQ_LEN, dev, lr=2e-4, b1=0.5, b2=0.999, lambda_gp=10.0, tau=0.5, hard=False,
                        n_critic=N_CRITIC, drop_rate=a.drop_rate, comm=comm)
+    if os.environ.get("S2G_NO_OVERLAP") == "1":
+        tr.D.overlap = False                                      # one stream, launch after launch (debugging aid)
     tr.G.load(common.generator_params(801, V, GEN_SEQ_LEN))      # same initial weights on every rank
     tr.D.load(common.critic_params(802, vocab=V))
     torch.manual_seed(42 + rank)                                  # per-rank noise streams
