@@ -46,9 +46,9 @@ def make_batches(seed: int, n: int, B: int, device, profile: str):
 
 def cpu_baseline(seconds_budget: float = 60.0):
     """The CPU restatement of the reference step (oracle/, pinned to the reference's outputs by
-    tests/test_oracle_golden.py) timed on this host: ONE critic iteration (wgan_gp.py:277-318) at
-    B = 64, L = 512, V = 175, generator seq_len 512 -- a bounded sample of the same workload (a
-    full step is 5 of these + a generator update that costs <1% of one on the CPU)."""
+    tests/test_oracle_golden.py) timed on this host: a few critic iterations (wgan_gp.py:277-318, about
+    12 s of CPU work) at B = 64, L = 512, V = 175, generator seq_len 512 -- a bounded sample of the same
+    workload (a full step is 5 of these + a generator update that costs <1% of one on the CPU)."""
     import common
     from oracle import wgan_gp_cpu as O
     threads = torch.get_num_threads()
