@@ -162,21 +162,22 @@ def test_full_size_iteration_matches_reference_golden(golden, tag):
 
 
 def test_full_step_streams_and_prefetch_are_bit_exact():
-    """full_step (own stream, CU-masked second stream beside the second-order sweeps, next fake batch
-    prefetched) must give exactly the bits of the same launches issued one after the other on one
-    stream: same kernels, same split-K slabs, only the schedule differs."""
+    """full_step (own stream, CU-masked streams beside the second-order sweeps, next fake batch and the
+    generator step's forward made ahead, one-batch lookahead across steps) must give exactly the bits
+    of the same launches issued one after the other on one stream: same kernels, same split-K slabs,
+    only the schedule differs.  Two full steps, so that the lookahead path is taken."""
     from s2g.trainer import WGANGPTrainer
     Tf, B, T = 24, 8, 32
     pg, pd = common.generator_params(901, 175, Tf), common.critic_params(902, scale=1.5)
-    batches = [dev_batch(*common.batch(910 + i, B, T, min_len=3)) for i in range(5)]
+    batches = [dev_batch(*common.batch(910 + i, B, T, min_len=3)) for i in range(10)]
     noises = []
-    for i in range(5):
+    for i in range(10):
         nz = {n: v.to(DEV) for n, v in common.noise(920 + i, B, Tf).items()}
         nz["alpha"] = nz["alpha"].view(-1).contiguous()
         nz["mask"] = (torch.rand(3 * B * T, 52, generator=common.gen(930 + i)) > 0.3).float().div(0.7).to(DEV)
         noises.append(nz)
-    mask_g = (torch.rand(B * Tf, 52, generator=common.gen(940)) > 0.3).float().div(0.7).to(DEV)
-    noises[0]["mask_g"] = mask_g
+    for i in (0, 5):
+        noises[i]["mask_g"] = (torch.rand(B * Tf, 52, generator=common.gen(940 + i)) > 0.3).float().div(0.7).to(DEV)
 
     serial = WGANGPTrainer(175, Tf, DEV, drop_rate=0.3)
     serial.G.load(pg); serial.D.load(pd)
@@ -184,12 +185,14 @@ def test_full_step_streams_and_prefetch_are_bit_exact():
     for i, (tok, lab, ln, wsum) in enumerate(batches):
         nz = noises[i]
         serial.critic_step(tok, lab, ln, wsum, nz["z"], nz["U"], nz["alpha"], nz["mask"])
-        if i == 0:
-            serial.generator_step(U=nz["U2"], mask=mask_g)
+        if i % 5 == 0:
+            serial.generator_step(U=nz["U2"], mask=nz["mask_g"])
 
     fused = WGANGPTrainer(175, Tf, DEV, drop_rate=0.3)
     fused.G.load(pg); fused.D.load(pd)
-    fused.full_step(batches, noises)
+    fused.full_step(batches[:5], noises[:5], lookahead=batches[5], lookahead_noise=noises[5])
+    assert fused._prefetched is not None, "the lookahead batch was not prefetched"
+    fused.full_step(batches[5:], noises[5:])
     torch.cuda.synchronize()
     if fused.D._side is False:
         pytest.skip("the runtime refused the CU-masked stream: nothing overlaps on this box")
