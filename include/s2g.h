@@ -128,11 +128,14 @@ int s2g_lstm2_bwd(const S2GSeq* seqs, int nseq, int rows_per_seq, const float* m
                   float* bsum, void* stream);
 /* tangent (forward-mode) sweep along an input direction whose projection is Xdot [rows, 200];
  * with s2g_lstm2_bwd2 it replaces the double backward that create_graph=True makes autograd
- * run for the gradient penalty (wgan_gp.py:251, 256, 317). */
+ * run for the gradient penalty (wgan_gp.py:251, 256, 317).  With gp_partial (the [nseq,4] output
+ * of s2g_gp_dots) sequence b's direction is Xdot_b times the penalty coefficient
+ * gp_upstream * 2 (|g_b| - 1) / (gp_n_batch |g_b|), evaluated by the sweep itself; NULL: Xdot as is. */
 int s2g_lstm2_tangent(const S2GSeq* seqs, int nseq, const float* Xdot, const float* mask, const float* whh0,
                       const float* wih1, const float* whh1, const float* gates0, const float* cell0,
                       const float* gates1, const float* cell1, float* adot0, float* celld0, float* adot1,
-                      float* celld1, float* hdotT, void* stream);
+                      float* celld1, float* hdotT, const float* gp_partial, float gp_upstream, float gp_n_batch,
+                      void* stream);
 int s2g_lstm2_bwd2(const S2GSeq* seqs, int nseq, int rows_per_seq, const float* mask, const float* whh0,
                    const float* wih1, const float* whh1, const float* gates0, const float* cell0,
                    const float* gates1, const float* cell1, const float* adot0, const float* celld0,
@@ -186,6 +189,11 @@ int s2g_gp_norm_penalty(float* g, int B, long per_sample, float upstream, float 
  * exist yet; pv_b <- coef_b * pv_b in place (the projected direction the tangent sweep consumes) */
 int s2g_gp_norm_penalty_proj(const float* delta, float* pv, int B, long per_sample, float upstream,
                              float n_batch, float* pen, float* norms, void* stream);
+/* the reduction of s2g_gp_norm_penalty_proj alone, in four blocks per sample and with pv left
+ * unscaled: partial[b][q] = sum over the q-th quarter of sample b of delta . pv; the tangent sweep
+ * takes the coefficient from the partials, s2g_gp_penalty_final gives pen / norms (wgan_gp.py:255-256) */
+int s2g_gp_dots(const float* delta, const float* pv, int B, long per_sample, float* partial, void* stream);
+int s2g_gp_penalty_final(const float* partial, int B, float* pen, float* norms, void* stream);
 int s2g_gp_scale(const float* g, const float* norms, const float* upstream, float n_batch, long per_sample,
                  float* v, int B, void* stream);
 

@@ -374,6 +374,44 @@ extern "C" __global__ __launch_bounds__(1024) void s2g_k_gp_norm_penalty_proj(
   }
 }
 
+// The reduction alone, in four blocks per sample (grid (B, 4)) and with pv left unscaled:
+// partial[b][q] = sum over the q-th quarter of sample b of delta . pv.  The tangent sweep adds the four
+// partials itself (gp_coef_from_partials) and scales its seed; s2g_k_gp_penalty_final turns them into
+// pen / norms off the critical path.  Both add in the same fixed order.
+extern "C" __global__ __launch_bounds__(1024) void s2g_k_gp_dots(const float* __restrict__ delta,
+                                                                 const float* __restrict__ pv, long per_sample,
+                                                                 float* __restrict__ partial) {
+  __shared__ float red[16];
+  const int b = blockIdx.x, q = blockIdx.y;
+  const float4* d4 = reinterpret_cast<const float4*>(delta + (long)b * per_sample);
+  const float4* p4 = reinterpret_cast<const float4*>(pv + (long)b * per_sample);
+  const long n4 = per_sample >> 2;
+  const long lo = n4 * q / 4, hi = n4 * (q + 1) / 4;
+  float s0 = 0.0f, s1 = 0.0f;
+  for (long i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    const float4 d = d4[i], p = p4[i];
+    s0 = fmaf(d.x, p.x, s0); s1 = fmaf(d.y, p.y, s1); s0 = fmaf(d.z, p.z, s0); s1 = fmaf(d.w, p.w, s1);
+  }
+  float s = row16_sum(s0 + s1);
+  s += __shfl_xor(s, 16);
+  s += __shfl_xor(s, 32);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.0f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += red[w];
+    partial[b * 4 + q] = tot;
+  }
+}
+extern "C" __global__ void s2g_k_gp_penalty_final(const float* __restrict__ partial, int B,
+                                                  float* __restrict__ pen, float* __restrict__ norms) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float nb = gp_norm_from_partials(partial + 4 * b);
+  pen[b] = (nb - 1.0f) * (nb - 1.0f);
+  if (norms) norms[b] = nb;
+}
+
 // v_b = coef_b * g_b with coef_b = upstream * 2 (n_b - 1) / (n_batch * n_b), out of place
 // (used when the upstream gradient only becomes known in a later backward call).
 extern "C" __global__ void s2g_k_gp_scale(const float* __restrict__ g, const float* __restrict__ norms,

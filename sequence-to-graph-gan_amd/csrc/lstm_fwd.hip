@@ -312,7 +312,8 @@ extern "C" __global__ __launch_bounds__(FWD_THREADS) void s2g_k_lstm2_tangent(
     const float* __restrict__ whh0, const float* __restrict__ wih1, const float* __restrict__ whh1,
     const float* __restrict__ gates0, const float* __restrict__ cell0, const float* __restrict__ gates1,
     const float* __restrict__ cell1, float* __restrict__ adot0, float* __restrict__ celld0,
-    float* __restrict__ adot1, float* __restrict__ celld1, float* __restrict__ hdotT) {
+    float* __restrict__ adot1, float* __restrict__ celld1, float* __restrict__ hdotT,
+    const float* __restrict__ gp_partial, float gp_upstream, float gp_n_batch) {
   __shared__ __attribute__((aligned(16))) float lds[FWD_LDS_FLOATS];
   float* h0buf = lds;                 // hdot of layer 0 [2][HV]
   float* h1buf = lds + 2 * HV;        // hdot of layer 1 [2][HV]
@@ -391,6 +392,11 @@ extern "C" __global__ __launch_bounds__(FWD_THREADS) void s2g_k_lstm2_tangent(
 #pragma unroll
   for (int j = 0; j < PF; ++j) ISSUE_C(j, j - lag)
 
+  // gp_partial (optional): Xdot holds the UNSCALED projected direction M2 delta of the gradient
+  // penalty; its per-sample factor comes from the four partial sums of |g|^2 (s2g_k_gp_dots), so no
+  // scaling pass over Xdot sits between the reverse sweep and this one
+  const float seed_scale =
+      gp_partial ? gp_coef_from_partials(gp_partial + 4 * blockIdx.x, gp_upstream, gp_n_batch) : 1.0f;
   float cd = 0.0f;      // cdot carried
   float cprev = 0.0f;   // primal c_{t-1} carried
   for (int base = 0; base < nit; base += PF) {
@@ -401,7 +407,7 @@ extern "C" __global__ __launch_bounds__(FWD_THREADS) void s2g_k_lstm2_tangent(
         const int t = tau - lag;
         if (t >= 0 && t < len) {
           f2 init;
-          if (l0) init = (f2){rx[j].x, rx[j].y};
+          if (l0) init = (f2){seed_scale * rx[j].x, seed_scale * rx[j].y};
           else {
             const float2 pin = *reinterpret_cast<const float2*>(p1buf + (t & 1) * 256 + lo2);
             init = (f2){pin.x, pin.y};

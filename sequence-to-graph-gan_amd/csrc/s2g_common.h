@@ -56,6 +56,17 @@ __device__ __forceinline__ void ce_on_probs(float z0, float z1, int y, float w0,
   dz1 = p1 * (dp1 - dot);
 }
 
+// Gradient-penalty scalars of one sample from its four partial sums of |g|^2 (s2g_k_gp_dots):
+// n = |g| and coef = upstream * 2 (n - 1) / (n_batch * n), the factor on g in d(penalty)/d(...)
+// (wgan_gp.py:255-256).  One fixed order of additions wherever these are evaluated.
+__device__ __forceinline__ float gp_norm_from_partials(const float* p) {
+  return sqrtf(fmaxf((p[0] + p[1]) + (p[2] + p[3]), 0.0f));
+}
+__device__ __forceinline__ float gp_coef_from_partials(const float* p, float upstream, float n_batch) {
+  const float nb = gp_norm_from_partials(p);
+  return nb > 0.0f ? upstream * 2.0f * (nb - 1.0f) / (n_batch * nb) : 0.0f;
+}
+
 // ---- DPP cross-lane helpers (64-wide wave, 16-lane DPP rows) ---------------------------------
 #define DPP_QUAD(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
 #define DPP_ROW_MIRROR 0x140

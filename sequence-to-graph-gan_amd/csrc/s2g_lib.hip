@@ -153,12 +153,26 @@ int s2g_lstm2_bwd(const S2GSeq* seqs, int nseq, int rows_per_seq, const float* m
 int s2g_lstm2_tangent(const S2GSeq* seqs, int nseq, const float* Xdot, const float* mask, const float* whh0,
                       const float* wih1, const float* whh1, const float* gates0, const float* cell0,
                       const float* gates1, const float* cell1, float* adot0, float* celld0, float* adot1,
-                      float* celld1, float* hdotT, void* stream) {
+                      float* celld1, float* hdotT, const float* gp_partial, float gp_upstream, float gp_n_batch,
+                      void* stream) {
   if (!seqs || nseq <= 0 || !Xdot) return -1;
   if (!whh0 || !wih1 || !whh1 || !gates0 || !cell0 || !gates1 || !cell1) return -1;
   if (!adot0 || !celld0 || !adot1 || !celld1 || !hdotT) return -1;
+  if (gp_partial && !(gp_n_batch > 0.0f)) return -1;
   hipLaunchKernelGGL(s2g_k_lstm2_tangent, dim3(nseq), dim3(FWD_THREADS), 0, ST(stream), seqs, Xdot, mask, whh0, wih1,
-                     whh1, gates0, cell0, gates1, cell1, adot0, celld0, adot1, celld1, hdotT);
+                     whh1, gates0, cell0, gates1, cell1, adot0, celld0, adot1, celld1, hdotT, gp_partial, gp_upstream,
+                     gp_n_batch);
+  return LAUNCH_OK();
+}
+int s2g_gp_dots(const float* delta, const float* pv, int B, long per_sample, float* partial, void* stream) {
+  if (!delta || !pv || !partial || B <= 0 || per_sample <= 0 || (per_sample & 3)) return -1;
+  if (((uintptr_t)delta | (uintptr_t)pv) & 15) return -1;
+  hipLaunchKernelGGL(s2g_k_gp_dots, dim3(B, 4), dim3(1024), 0, ST(stream), delta, pv, per_sample, partial);
+  return LAUNCH_OK();
+}
+int s2g_gp_penalty_final(const float* partial, int B, float* pen, float* norms, void* stream) {
+  if (!partial || !pen || B <= 0) return -1;
+  hipLaunchKernelGGL(s2g_k_gp_penalty_final, dim3(cdiv(B, 64)), dim3(64), 0, ST(stream), partial, B, pen, norms);
   return LAUNCH_OK();
 }
 

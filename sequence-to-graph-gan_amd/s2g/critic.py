@@ -138,7 +138,7 @@ class CriticEngine:
             ws.update(adj0=z(so_rows, 2 * H), adj1=z(so_rows, 2 * H), adot0=z(so_rows, G4), adot1=z(so_rows, G4),
                       celld0=z(so_rows, G4), celld1=z(so_rows, G4), abar0=z(so_rows, G4), abar1=z(so_rows, G4),
                       hdotT=z(so_seqs, H), G=z(so_rows, self.V), Pv=z(so_rows, G4), pen=z(so_seqs),
-                      norms=z(so_seqs), bsumB=z(2, nseq, G4), bsumD=z(2, so_seqs, G4))
+                      norms=z(so_seqs), gp_partial=z(so_seqs, 4), bsumB=z(2, nseq, G4), bsumD=z(2, so_seqs, G4))
         return ws
 
     def workspace_g(self, B: int, Tf: int) -> Dict[str, torch.Tensor]:
@@ -257,14 +257,17 @@ class CriticEngine:
              max(adj_seq0, 0), max(adj_seq0, 0) * Tw, ctypes.byref(head) if head is not None else None,
              ptr(bsum), stream_ptr())
 
-    def sweep_tangent(self, ws, desc_ptr, nseq, mask_ptr, row0: int) -> None:
-        """Sequences of `desc` count rows from workspace row `row0` (their descriptors are relative)."""
+    def sweep_tangent(self, ws, desc_ptr, nseq, mask_ptr, row0: int, gp=None) -> None:
+        """Sequences of `desc` count rows from workspace row `row0` (their descriptors are relative).
+        gp = (partial [nseq,4], upstream, n_batch): the sweep scales sequence b's direction by the penalty
+        coefficient it derives from the partial sums of |g_b|^2; None: ws["Pv"] is the direction as is."""
         whh0, wih1, whh1 = self._w()
         o = row0 * G4
+        part, up, nb = gp if gp is not None else (None, 0.0, 1.0)
         call("s2g_lstm2_tangent", desc_ptr, nseq, ptr(ws["Pv"]), mask_ptr, whh0, wih1, whh1,
              ptr(ws["gates0"], o), ptr(ws["cell0"], o), ptr(ws["gates1"], o), ptr(ws["cell1"], o),
              ptr(ws["adot0"]), ptr(ws["celld0"]), ptr(ws["adot1"]), ptr(ws["celld1"]), ptr(ws["hdotT"]),
-             stream_ptr())
+             ptr(part), float(up), float(nb), stream_ptr())
 
     def sweep_bwd2(self, ws, desc_ptr, nseq, Tw, mask_ptr, row0: int, bsum: Optional[torch.Tensor] = None) -> None:
         """bsum [2, nseq, 200]: receives every sequence's sums over time of abar0 / abar1."""
@@ -477,8 +480,10 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
     # beside sweep C (first_order below).
     r_int = 2 * B * Tw
     ops.gemm_tall(ptr(ws["delta0"], r_int * G4), G4, ptr(eng.m2()), G4, ptr(ws["Pv"]), G4, B * Tw, G4, G4)
-    call("s2g_gp_norm_penalty_proj", ptr(ws["delta0"], r_int * G4), ptr(ws["Pv"]), B, Tw * G4, float(lambda_gp),
-         float(n_global), ptr(ws["pen"]), ptr(ws["norms"]), st)
+    # only the reduction stays on the critical path: sweep C scales its own seed by coef_b, and the
+    # penalty values / norms come out beside it (first_order)
+    call("s2g_gp_dots", ptr(ws["delta0"], r_int * G4), ptr(ws["Pv"]), B, Tw * G4, ptr(ws["gp_partial"]), st)
+    gp = (ws["gp_partial"], float(lambda_gp), float(n_global))
     lam = eng.device_scalar(float(lambda_gp))
     d0, d1, c0, c1 = ws["delta0"], ws["delta1"], ws["cell0"], ws["cell1"]
     a0, a1, cd0, cd1 = ws["abar0"], ws["abar1"], ws["celld0"], ws["celld1"]
@@ -510,6 +515,7 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         """Everything that needs sweeps A and B only: operands of the products, their phase-0 part, the
         first-order bias gradients."""
         s_ = stream_ptr()
+        call("s2g_gp_penalty_final", ptr(ws["gp_partial"]), B, ptr(ws["pen"]), ptr(ws["norms"]), s_)
         # v = coef_b * (delta0 W_ih0): the direction of the penalty's second-order term in input space
         ops.gemm_tall(ptr(ws["delta0"], r_int * G4), G4, ptr(eng.W0p), eng.Vp, ptr(ws["G"]), V, B * Tw, V, G4)
         call("s2g_gp_scale", ptr(ws["G"]), ptr(ws["norms"]), ptr(lam), float(n_global), Tw * V, ptr(ws["G"]), B, s_)
@@ -555,7 +561,7 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         with torch.cuda.stream(sweeps):
             if not own:
                 stream_c.wait_event(fork)
-            eng.timed("s2g_k_lstm2_tangent", lambda: eng.sweep_tangent(ws, drel, B, mrel, r_int))
+            eng.timed("s2g_k_lstm2_tangent", lambda: eng.sweep_tangent(ws, drel, B, mrel, r_int, gp))
             after_c.record()
         # the small launch-bound pieces (loss values + fc gradients, first-order bias sums) go beside the
         # operand / product chain of stream2, which must be through before sweep D is
@@ -603,7 +609,7 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         _wgrad_reduce(eng, built)
         cur.wait_event(join_c)
     else:
-        eng.timed("s2g_k_lstm2_tangent", lambda: eng.sweep_tangent(ws, drel, B, mrel, r_int))
+        eng.timed("s2g_k_lstm2_tangent", lambda: eng.sweep_tangent(ws, drel, B, mrel, r_int, gp))
         eng.timed("s2g_k_lstm2_bwd2", lambda: eng.sweep_bwd2(ws, drel, B, Tw, mrel, r_int, bsum=ws["bsumD"]))
         head_losses()
         first_order(sc)

@@ -54,7 +54,7 @@ SIGNATURES = {
     "s2g_bias_sums_final": [P, I, L, P, I, P, P, P, P, P, I, P],
     "s2g_lstm2_fwd": [P, I, I] + [P] * 15,
     "s2g_lstm2_bwd": [P, I, I] + [P] * 13 + [I, I, P, P, P],
-    "s2g_lstm2_tangent": [P, I] + [P] * 15,
+    "s2g_lstm2_tangent": [P, I] + [P] * 14 + [P, F, F, P],
     "s2g_lstm2_bwd2": [P, I, I] + [P] * 18,
     "s2g_pack_critic": [P] * 9 + [I, P],
     "s2g_critic_batch_desc": [P, P, I, I, I, I, P, P],
@@ -69,6 +69,8 @@ SIGNATURES = {
     "s2g_gp_interp_dense": [P, P, P, P, I, I, I, I, P, P],
     "s2g_gp_norm_penalty": [P, I, L, F, F, P, P, I, P],
     "s2g_gp_norm_penalty_proj": [P, P, I, L, F, F, P, P, P],
+    "s2g_gp_dots": [P, P, I, L, P, P],
+    "s2g_gp_penalty_final": [P, I, P, P, P],
     "s2g_gp_scale": [P, P, P, F, L, P, I, P],
     "s2g_embed_mul": [P, P, P, P, I, I, P],
     "s2g_embed_mul_bwd": [P, P, P, P, I, I, I, P],

@@ -76,6 +76,16 @@ def test_gp_norm_penalty_proj_matches_formula():
     assert rel(pen.cpu(), (n - 1) ** 2) < TOL
     coef = lam * 2 * (n - 1) / (nb * n)
     assert rel(pv.cpu().view(B, -1), pv0.double().cpu().view(B, -1) * coef[:, None]) < TOL
+    # the reduction alone (four partial sums per sample, pv untouched) and the values from the partials
+    part = torch.empty(B, 4, device=DEV)
+    pen2, norms2 = torch.empty(B, device=DEV), torch.empty(B, device=DEV)
+    call("s2g_gp_dots", ptr(delta), ptr(pv0), B, T * 200, ptr(part), stream_ptr())
+    call("s2g_gp_penalty_final", ptr(part), B, ptr(pen2), ptr(norms2), stream_ptr())
+    torch.cuda.synchronize()
+    assert rel(part.double().sum(1).cpu(), n ** 2) < TOL
+    assert rel(norms2.cpu(), n) < TOL
+    assert rel(pen2.cpu(), (n - 1) ** 2) < TOL
+    assert rel(norms2.cpu(), ((part[:, 0] + part[:, 1]) + (part[:, 2] + part[:, 3])).clamp_min(0).sqrt().cpu()) < 1e-6
 
 
 def test_reduce_slabs_multi_matches_single():

@@ -100,6 +100,20 @@ def test_four_sweeps_match_oracle(B, T, ragged, with_mask, scale):
     assert_close(ws["abar1"].cpu().view(B, T, 200), to_internal(A["abar1"]), TOL, "abar1")
     assert_close(ws["abar0"].cpu().view(B, T, 200), to_internal(A["abar0"]), TOL, "abar0")
 
+    # the sweep scaling its own direction by the penalty coefficient of each sequence: the tangent
+    # states are linear in the direction
+    plain = {k: ws[k].clone() for k in ("adot0", "adot1", "celld1", "hdotT")}
+    part = (torch.rand(B, 4, generator=common.gen(77)) * 2.0).to(dev)
+    lam, nb = 10.0, 7.0
+    eng.sweep_tangent(ws, ptr(desc), B, ptr(mk), 0, gp=(part, lam, nb))
+    torch.cuda.synchronize()
+    n = part.double().sum(1).sqrt()
+    coef = (lam * 2 * (n - 1) / (nb * n)).cpu()
+    assert_close(ws["hdotT"].cpu(), plain["hdotT"].cpu().double() * coef[:, None], TOL, "hdotT scaled")
+    for k in ("adot0", "adot1", "celld1"):
+        want = plain[k].cpu().double().view(B, -1) * coef[:, None]
+        assert_close(ws[k].cpu().view(B, -1), want, TOL, k + " scaled")
+
 
 @pytest.mark.parametrize("mode", [0, 1])
 def test_reverse_sweep_with_inline_head_matches_head_kernels(mode):
