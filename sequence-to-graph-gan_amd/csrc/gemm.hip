@@ -22,6 +22,7 @@
 #define LDS_LD 68   // k-major tiles [BK][64 + 4]: 16-byte rows, float4 stores stay aligned
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Operand pointers reach the kernels inside a struct (for the grouped launch, a struct read from
 // memory), where the compiler cannot prove they are global: it would emit flat loads, which also
@@ -551,30 +552,37 @@ extern "C" __global__ __launch_bounds__(256) void s2g_k_bias_sums_final(
 }
 
 // Tall product C[M,N] = A[M,K] B[K,N] with M = all sequence-steps and K, N <= 224 (the input
-// projection x W_ih0^T, its transpose delta W_ih0 and delta (W_ih0 W_ih0^T)): a block of four waves
-// (one per SIMD) owns 128 rows and ALL N columns, so A is read exactly once and B (<= 160 KB, L2-resident) once per
-// block.  Wave w keeps NT 32x32 accumulators for rows [32w, 32w+32); per k-pair one A fragment feeds
-// NT MFMAs.  K is streamed in chunks of 32 through two LDS stages (one barrier per chunk); the next
-// chunk's global loads are issued between the MFMAs of the current one (the wave issues in order).
+// projection x W_ih0^T, its transpose delta W_ih0 and delta (W_ih0 W_ih0^T)): a block owns 128 rows and
+// ALL N columns, so A is read exactly once and B (<= 160 KB, L2-resident) once per block.  Eight waves
+// per block (two per SIMD, so one wave's LDS reads, chunk hand-over and stores run under the other's
+// MFMAs): wave w owns rows [16w, 16w+16) as NT16 16x16 accumulators (N is padded to 16).  Per k-quad
+// one A fragment feeds NT16 MFMAs (v_mfma_f32_16x16x4_f32: lane l supplies A[l%16][l/16] and
+// B[l/16][l%16], holds D[4(l/16)+r][l%16]).  K is streamed in chunks of 32 through two LDS stages (one
+// barrier per chunk); the next chunk's global loads are issued between the MFMAs of the current one.
+// LDS rows: A stride 34 floats (banks 2*row + k: no conflicts among the 32 lanes of a half wave), B
+// stride = 16 mod 32 floats (two consecutive k rows land on disjoint halves of the banks).
 // A: row-major, k contiguous (any lda, rows may be unaligned: lanes run along k).  B: row-major with
 // ldb % 4 == 0, 16-byte aligned, readable up to column roundup(N, 4) (pad columns must hold zeros).
+// Register-only MFMA loops reach 156 TFLOP/s on this part (tools/mfma_peak.hip); this kernel's MFMA
+// phase is 15-17 us of its 33-36 us at M = 32768, the rest being launch, first-chunk latency, the chunk
+// hand-overs and the C stores, none of which another block hides (one block per CU, one round).
 #define TALL_ROWS 128
-#define TALL_ALD 33
-template <int NT>
-__global__ __launch_bounds__(256) void s2g_k_gemm_tall(const float* __restrict__ A, long lda,
-                                                       const float* __restrict__ B, long ldb,
-                                                       float* __restrict__ C, long ldc, int M, int N, int K) {
-  constexpr int BLD = NT * 32 + 4;            // B stage row length (floats)
-  constexpr int NC4 = NT * 8;                 // float4 per B stage row
-  constexpr int NB = (32 * NC4 + 255) / 256;  // B float4 loads per thread per chunk
-  constexpr int STAGE = TALL_ROWS * TALL_ALD + 32 * BLD;
+#define TALL16_ALD 34
+template <int NT16>
+__global__ __launch_bounds__(512) void s2g_k_gemm_tall16(const float* __restrict__ A, long lda,
+                                                         const float* __restrict__ B, long ldb,
+                                                         float* __restrict__ C, long ldc, int M, int N, int K) {
+  constexpr int BLD = NT16 * 16 + ((NT16 & 1) ? 0 : 16);   // B stage row length (floats)
+  constexpr int NC4 = NT16 * 4;                             // float4 per B stage row
+  constexpr int NB = (32 * NC4 + 511) / 512;                // B float4 loads per thread per chunk
+  constexpr int STAGE = TALL_ROWS * TALL16_ALD + 32 * BLD;
   extern __shared__ __attribute__((aligned(16))) float tall_lds[];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int m0 = blockIdx.x * TALL_ROWS;
-  const int ar = tid >> 5, ak = tid & 31;     // A loader: rows ar + 8e (e < 16), column k0 + ak
+  const int ar = tid >> 5, ak = tid & 31;     // A loader: rows ar + 16e (e < 8), column k0 + ak
 
-  float ra[16];
+  float ra[8];
   float4 rb[NB];
   int kf = 0;                                 // first k of the chunk being fetched
   // Out-of-range elements read element 0 and are zeroed only when the chunk is written to LDS (bit
@@ -582,14 +590,14 @@ __global__ __launch_bounds__(256) void s2g_k_gemm_tall(const float* __restrict__
   // MFMA loop.
   unsigned liveA = 0, liveB = 0;
   auto fetch_a = [&](int e) {
-    const int row = m0 + ar + 8 * e, k = kf + ak;
+    const int row = m0 + ar + 16 * e, k = kf + ak;
     const bool in = row < M && k < K;
     ra[e] = gload(A + (in ? (long)row * lda + k : 0));
     if (e == 0) liveA = 0;
     liveA |= in ? (1u << e) : 0u;
   };
   auto fetch_b = [&](int e) {
-    const int f = tid + 256 * e;
+    const int f = tid + 512 * e;
     const int kr = f / NC4, c4 = f - kr * NC4;
     const bool in = f < 32 * NC4 && kf + kr < K && 4 * c4 < N;
     rb[e] = gload4(B + (in ? (long)(kf + kr) * ldb + 4 * c4 : 0));
@@ -598,28 +606,26 @@ __global__ __launch_bounds__(256) void s2g_k_gemm_tall(const float* __restrict__
   };
   auto store = [&](float* S) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) S[(ar + 8 * e) * TALL_ALD + ak] = (liveA >> e) & 1u ? ra[e] : 0.0f;
+    for (int e = 0; e < 8; ++e) S[(ar + 16 * e) * TALL16_ALD + ak] = (liveA >> e) & 1u ? ra[e] : 0.0f;
 #pragma unroll
     for (int e = 0; e < NB; ++e) {
-      const int f = tid + 256 * e;
+      const int f = tid + 512 * e;
       const int kr = f / NC4, c4 = f - kr * NC4;
       const bool l = (liveB >> e) & 1u;
       float4 v;
       v.x = l ? rb[e].x : 0.0f; v.y = l ? rb[e].y : 0.0f; v.z = l ? rb[e].z : 0.0f; v.w = l ? rb[e].w : 0.0f;
-      if (f < 32 * NC4) *reinterpret_cast<float4*>(S + TALL_ROWS * TALL_ALD + kr * BLD + 4 * c4) = v;
+      if (f < 32 * NC4) *reinterpret_cast<float4*>(S + TALL_ROWS * TALL16_ALD + kr * BLD + 4 * c4) = v;
     }
   };
 
-  f32x16 acc[NT];
+  f32x4 acc[NT16];
 #pragma unroll
-  for (int j = 0; j < NT; ++j)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[j][i] = 0.0f;
-  const int aoff = (32 * wave + (lane & 31)) * TALL_ALD + (lane >> 5);
-  const int boff = TALL_ROWS * TALL_ALD + (lane >> 5) * BLD + (lane & 31);
+  for (int j = 0; j < NT16; ++j) acc[j] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+  const int aoff = (16 * wave + (lane & 15)) * TALL16_ALD + (lane >> 4);
+  const int boff = TALL_ROWS * TALL16_ALD + (lane >> 4) * BLD + (lane & 15);
 
 #pragma unroll
-  for (int e = 0; e < 16; ++e) fetch_a(e);
+  for (int e = 0; e < 8; ++e) fetch_a(e);
 #pragma unroll
   for (int e = 0; e < NB; ++e) fetch_b(e);
   store(tall_lds);
@@ -628,17 +634,46 @@ __global__ __launch_bounds__(256) void s2g_k_gemm_tall(const float* __restrict__
   for (int k0 = 0; k0 < K; k0 += 32) {
     const float* S = tall_lds + cur * STAGE;
     kf = k0 + 32;                             // past the last chunk every fetch is masked
+    // Fragments are double-buffered in registers: the LDS reads of quad q+1 are issued before the MFMAs
+    // of quad q.  Dead k (>= K) holds zeros in both operands; a chunk whose second half is dead skips it.
+    float a0, a1, b0[NT16], b1[NT16];
+    auto frag = [&](int q, float& a, float (&b)[NT16]) {
+      a = S[aoff + 4 * q];
 #pragma unroll
-    for (int kk = 0; kk < 32; kk += 2) {
-      if (kk < 16) {                          // all fetches in the first half: they land before the store
-        fetch_a(kk);
-        fetch_a(kk + 1);
-        if ((kk >> 1) < NB) fetch_b(kk >> 1);
+      for (int j = 0; j < NT16; ++j) b[j] = S[boff + 4 * q * BLD + 16 * j];
+    };
+    auto mma = [&](float a, const float (&b)[NT16]) {
+#pragma unroll
+      for (int j = 0; j < NT16; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[j], acc[j], 0, 0, 0);
+    };
+    frag(0, a0, b0);
+#pragma unroll
+    for (int q = 0; q < 4; q += 2) {          // all fetches in the first half: they land before the store
+#pragma unroll
+      for (int e = 0; e < 4; ++e) fetch_a(2 * q + e);
+      if (q < NB) fetch_b(q);
+      if (q + 1 < NB) fetch_b(q + 1);
+      frag(q + 1, a1, b1);
+      __builtin_amdgcn_sched_barrier(0);      // keep the reads ahead of the MFMAs they do not feed
+      mma(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      frag(q + 2, a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (K - k0 > 16) {
+#pragma unroll
+      for (int q = 4; q < 8; q += 2) {
+        frag(q + 1, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (q + 2 < 8) frag(q + 2, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      const float a = S[aoff + kk];
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, S[boff + kk * BLD + 32 * j], acc[j], 0, 0, 0);
     }
     store(tall_lds + (cur ^ 1) * STAGE);      // the other stage: nobody reads it during this chunk
     __syncthreads();
@@ -646,12 +681,12 @@ __global__ __launch_bounds__(256) void s2g_k_gemm_tall(const float* __restrict__
   }
 
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int col = 32 * j + (lane & 31);
+  for (int j = 0; j < NT16; ++j) {
+    const int col = 16 * j + (lane & 15);
     if (col < N) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + 16 * wave + 4 * (lane >> 4) + r;
         if (row < M) C[(long)row * ldc + col] = acc[j][r];
       }
     }
@@ -660,22 +695,22 @@ __global__ __launch_bounds__(256) void s2g_k_gemm_tall(const float* __restrict__
 
 extern "C" int s2g_launch_gemm_tall(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M,
                                     int N, int K, hipStream_t stream) {
-  const int nt = (N + 31) / 32;
-  const dim3 grid((M + TALL_ROWS - 1) / TALL_ROWS), block(256);
-#define S2G_TALL_CASE(NT_)                                                                                   \
-  if (nt == NT_) {                                                                                           \
-    const size_t lds = 2 * (TALL_ROWS * TALL_ALD + 32 * (NT_ * 32 + 4)) * sizeof(float);                     \
-    static bool attr_done = false;                                                                           \
-    if (!attr_done) {                                                                                        \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&s2g_k_gemm_tall<NT_>),                          \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2; \
-      attr_done = true;                                                                                      \
-    }                                                                                                        \
-    hipLaunchKernelGGL((s2g_k_gemm_tall<NT_>), grid, block, lds, stream, A, lda, B, ldb, C, ldc, M, N, K);     \
-    return hipGetLastError() == hipSuccess ? 0 : -2;                                                         \
+  const int nt16 = (N + 15) / 16;
+  const dim3 grid((M + TALL_ROWS - 1) / TALL_ROWS), block(512);
+#define S2G_TALL16_CASE(NT_)                                                                                   \
+  if (nt16 <= NT_) {                                                                                           \
+    const size_t lds = 2 * (TALL_ROWS * TALL16_ALD + 32 * (NT_ * 16 + ((NT_ & 1) ? 0 : 16))) * sizeof(float);  \
+    static bool attr_done = false;                                                                             \
+    if (!attr_done) {                                                                                          \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&s2g_k_gemm_tall16<NT_>),                          \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;  \
+      attr_done = true;                                                                                        \
+    }                                                                                                          \
+    hipLaunchKernelGGL((s2g_k_gemm_tall16<NT_>), grid, block, lds, stream, A, lda, B, ldb, C, ldc, M, N, K);   \
+    return hipGetLastError() == hipSuccess ? 0 : -2;                                                           \
   }
-  S2G_TALL_CASE(6) S2G_TALL_CASE(7)
-#undef S2G_TALL_CASE
+  S2G_TALL16_CASE(11) S2G_TALL16_CASE(13) S2G_TALL16_CASE(14)
+#undef S2G_TALL16_CASE
   return -1;
 }
 

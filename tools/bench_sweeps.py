@@ -92,6 +92,18 @@ def main():
     res["bwd_64"] = timeit(lambda: eng.sweep_bwd(ws, ptr(desc), B, T, mask))
     res["tangent_64"] = timeit(lambda: eng.sweep_tangent(ws, ptr(desc, 3 * B * 8), B, mrel, r0))
     res["bwd2_64"] = timeit(lambda: eng.sweep_bwd2(ws, ptr(desc, 3 * B * 8), B, T, mrel, r0))
+    if "--tall" in sys.argv:
+        from s2g import ops
+        fake = torch.rand(B * T, V, device=dev)
+        Pf = torch.empty(B * T, 200, device=dev)
+        G = torch.empty(B * T, V, device=dev)
+        tall = {}
+        tall["project"] = timeit(lambda: eng.project(fake, Pf))
+        tall["delta_m2"] = timeit(lambda: ops.gemm_tall(ptr(ws["delta0"], r0 * 200), 200, ptr(eng.m2()), 200,
+                                                        ptr(ws["Pv"]), 200, B * T, 200, 200))
+        tall["delta_w0"] = timeit(lambda: ops.gemm_tall(ptr(ws["delta0"], r0 * 200), 200, ptr(eng.W0p), eng.Vp,
+                                                        ptr(G), V, B * T, V, 200))
+        print("tall products:", " ".join(f"{k}={v:.1f}us" for k, v in tall.items()))
     print(f"T={T} per-step ns:", " ".join(f"{k}={v * 1e3 / (T + 2):.0f}" for k, v in res.items()))
     print(" ".join(f"{k}={v:.1f}us" for k, v in res.items()), f"sum4={res['fwd_192'] + res['bwd_192'] + res['tangent_64'] + res['bwd2_64']:.1f}us")
 

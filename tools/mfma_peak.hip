@@ -1,0 +1,67 @@
+// Measures the sustained rate of the fp32 MFMA instructions from registers only (no memory traffic):
+// the practical ceiling for the exact-fp32 products of this repository.  Development aid.
+//   hipcc --offload-arch=gfx950 -O3 tools/mfma_peak.hip -o /tmp/mfma_peak && /tmp/mfma_peak
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int NACC>
+__global__ void k16(float* out, int iters, float a, float b) {
+  f32x4 acc[NACC];
+  for (int j = 0; j < NACC; ++j) acc[j] = (f32x4){0, 0, 0, 0};
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int j = 0; j < NACC; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[j], 0, 0, 0);
+  }
+  float s = 0;
+  for (int j = 0; j < NACC; ++j) s += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
+  if (s == 12345.0f) out[threadIdx.x] = s;
+}
+template <int NACC>
+__global__ void k32(float* out, int iters, float a, float b) {
+  f32x16 acc[NACC];
+  for (int j = 0; j < NACC; ++j)
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0;
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int j = 0; j < NACC; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+  }
+  float s = 0;
+  for (int j = 0; j < NACC; ++j)
+    for (int r = 0; r < 16; ++r) s += acc[j][r];
+  if (s == 12345.0f) out[threadIdx.x] = s;
+}
+
+template <typename F>
+static float timeit(F f) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  f();
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  f();
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  return ms;
+}
+
+int main() {
+  float* out;
+  hipMalloc(&out, 4096);
+  const int iters = 4000;
+  for (int threads : {256, 512, 1024}) {
+    for (int blocks : {256, 512}) {
+      float ms = timeit([&] { hipLaunchKernelGGL(k16<13>, dim3(blocks), dim3(threads), 0, 0, out, iters, 1.0f, 2.0f); });
+      double fl = (double)blocks * (threads / 64) * iters * 13 * 2048.0;
+      printf("16x16x4  blocks=%d threads=%d: %.3f ms  %.1f TFLOP/s\n", blocks, threads, ms, fl / ms * 1e-9);
+      ms = timeit([&] { hipLaunchKernelGGL(k32<7>, dim3(blocks), dim3(threads), 0, 0, out, iters, 1.0f, 2.0f); });
+      fl = (double)blocks * (threads / 64) * iters * 7 * 4096.0;
+      printf("32x32x2  blocks=%d threads=%d: %.3f ms  %.1f TFLOP/s\n", blocks, threads, ms, fl / ms * 1e-9);
+    }
+  }
+  return 0;
+}
