@@ -7,6 +7,7 @@ produced by kernels of libs2g (see include/s2g.h), torch only provides the memor
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, Optional
 
 import torch
@@ -314,11 +315,13 @@ def _wgrad(eng: "CriticEngine", out: torch.Tensor, N: int, terms) -> None:
 def _wgrad_build(eng: "CriticEngine", jobs, cache_key):
     """jobs: list of (out tensor [200,N] torch layout, N, terms); a term is
     (A_ptr, K, B_ptr, sbk, sbn, segT, a_seg, b_seg, shift[, phase]).  All products of one phase run
-    in ONE grouped GEMM launch; every product owns its split-K slabs, one reduce per job sums the
-    slabs of all phases.  Returns (tables {phase: (table, prefix, nprob, nblocks)}, job_slabs,
-    slabs); the device-side tables are cached per `cache_key` and rebuilt only when a pointer or
-    size changes."""
+    in ONE grouped GEMM launch; every product owns its split-K slabs.  The slabs of a job are laid out [phases before the last | one slot
+    for their sum | last phase], so the early reduce (phases before the last -> the slot) runs while the
+    last phase is still being computed and the final reduce reads the slot and the last phase only.
+    Returns (tables {phase: (table, prefix, nprob, nblocks)}, job_slabs, slabs); the device-side tables
+    are cached per `cache_key` and rebuilt only when a pointer or size changes."""
     from .lib import S2GGemm
+    last = max((term[9] if len(term) > 9 else 0) for _, _, terms in jobs for term in terms)
     # K-chunk per phase: 1024 rows unless that leaves the launch with fewer than ~3 blocks per CU
     # (the kernel hides its loads behind the MFMAs of the other blocks on the CU)
     chunk = {}
@@ -335,7 +338,8 @@ def _wgrad_build(eng: "CriticEngine", jobs, cache_key):
     base = 0
     for out, N, terms in jobs:
         slab = G4 * N
-        nsl = 0
+        tiles = (N + 63) // 64                               # (all 200 rows) x 64 output tiles
+        early, late = [], []
         for term in terms:
             A, K, B, sbk, sbn, segT, a_seg, b_seg, shift = term[:9]
             phase = term[9] if len(term) > 9 else 0
@@ -344,13 +348,21 @@ def _wgrad_build(eng: "CriticEngine", jobs, cache_key):
             c = chunk[phase]
             ns = max(1, min(256, (K + c // 2) // c))
             kchunk = ((K + ns - 1) // ns + 31) // 32 * 32
-            tiles = (N + 63) // 64                               # (all 200 rows) x 64 output tiles
-            plan.append((phase, A, K, B, sbk, sbn, segT, a_seg, b_seg, shift, N, kchunk, base + nsl * slab, slab,
-                         tiles * ns))
-            sig.append((phase, A, K, B, sbk, sbn, segT, a_seg, b_seg, shift, N))
-            nsl += ns
-        job_slabs.append((out, nsl, slab, base))
-        base += nsl * slab
+            (late if phase == last else early).append((phase, A, K, B, sbk, sbn, segT, a_seg, b_seg, shift, N, kchunk, ns))
+        n_early = sum(e[-1] for e in early)
+        n_late = sum(e[-1] for e in late)
+        pos = 0
+        for e in early:
+            plan.append(e[:-1] + (base + pos * slab, slab, tiles * e[-1]))
+            sig.append(e[:11])
+            pos += e[-1]
+        pos = n_early + (1 if n_early else 0)             # the slot for the early sum
+        for e in late:
+            plan.append(e[:-1] + (base + pos * slab, slab, tiles * e[-1]))
+            sig.append(e[:11])
+            pos += e[-1]
+        job_slabs.append((out, n_early, n_late, slab, base))
+        base += pos * slab
     if eng._wgrad_slabs is None or eng._wgrad_slabs.numel() < base:
         eng._wgrad_slabs = torch.empty(max(base, 1), dtype=torch.float32, device=eng.device)
     slabs = eng._wgrad_slabs
@@ -384,22 +396,34 @@ def _wgrad_launch(eng: "CriticEngine", built, phase: int) -> None:
                   lambda: call("s2g_gemm_grouped", ptr(raw), ptr(pre), nprob, nblocks, stream_ptr()))
 
 
-def _wgrad_reduce(eng: "CriticEngine", built) -> None:
+def _wgrad_reduce(eng: "CriticEngine", built, early: bool = False) -> None:
+    """early: sums every job's slabs of the phases before the last into the job's slot (internal row
+    order, may run beside the last phase); otherwise: slot + last phase -> the torch-layout gradient."""
     from .lib import S2GReduce
     _, job_slabs, slabs = built
-    live = [(out, nsl, slab, base) for out, nsl, slab, base in job_slabs if nsl]
+    live = []
+    for out, n_early, n_late, slab, base in job_slabs:
+        if early:
+            if n_early:
+                live.append((ptr(slabs, base), slab, ptr(slabs, base + n_early * slab), n_early))
+        elif n_early + n_late:
+            first = base + n_early * slab if n_early else base
+            live.append((ptr(slabs, first), slab, ptr(out), (1 if n_early else 0) + n_late))
     for i in range(0, len(live), 8):                    # one launch per 8 parameters
         part = live[i:i + 8]
         arr = (S2GReduce * len(part))()
-        for k, (out, nsl, slab, base) in enumerate(part):
-            arr[k] = S2GReduce(ptr(slabs, base), slab, ptr(out), nsl, G4, slab // G4)
-        call("s2g_reduce_slabs_multi", arr, len(part), 1, 0, 1.0, stream_ptr())
+        for k, (src, slab, dst, nsl) in enumerate(part):
+            arr[k] = S2GReduce(src, slab, dst, nsl, G4, slab // G4)
+        call("s2g_reduce_slabs_multi", arr, len(part), 0 if early else 1, 0, 1.0, stream_ptr())
 
 
 def _wgrad_grouped(eng: "CriticEngine", jobs, cache_key) -> None:
     built = _wgrad_build(eng, jobs, cache_key)
-    for ph in sorted(built[0]):
+    phases = sorted(built[0])
+    for ph in phases[:-1]:
         _wgrad_launch(eng, built, ph)
+    _wgrad_reduce(eng, built, early=True)
+    _wgrad_launch(eng, built, phases[-1])
     _wgrad_reduce(eng, built)
 
 
@@ -575,6 +599,7 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         with torch.cuda.stream(stream2):
             stream2.wait_event(after_c)
             _wgrad_launch(eng, built, 1)
+            _wgrad_reduce(eng, built, early=True)
             join.record()
             if prefetch is not None and eng.stream_g is None:
                 prefetch()          # not part of the join: it may run on beside this iteration's tail
@@ -615,6 +640,7 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         first_order(sc)
         first_order_sums(sc)
         _wgrad_launch(eng, built, 1)
+        _wgrad_reduce(eng, built, early=True)
         if prefetch is not None:
             prefetch()
         _wgrad_launch(eng, built, 2)

@@ -42,6 +42,48 @@ def test_gemm_tall_rejects_bad_shapes():
     assert L.s2g_gemm_tall(x.data_ptr(), 200, x.data_ptr(), 256, x.data_ptr(), 256, 64, 230, 200, s) == -1   # N > 224
 
 
+def test_gemm_grouped_matches_torch():
+    """Three weight-gradient products in one launch: a wide one on contiguous rows with a ragged K, a
+    narrow one whose B operand is strided (every 4th float) and reads the previous step inside each
+    sequence (zero at step 0), and a wide one whose operands keep a different number of rows per sequence."""
+    from s2g.lib import S2GGemm, call
+    from s2g.ops import ptr, stream_ptr
+    g = common.gen(21)
+    nb, T, Tw = 5, 37, 41
+    K1 = 1003
+    A1 = torch.randn(K1, 200, generator=g).to(DEV)
+    B1 = torch.randn(K1, 175, generator=g).to(DEV)
+    A2 = torch.randn(nb * Tw, 200, generator=g).to(DEV)
+    cell = torch.randn(nb * Tw, 50, 4, generator=g).to(DEV)
+    A3 = torch.randn(nb * Tw, 200, generator=g).to(DEV)
+    B3 = torch.randn(nb * T, 175, generator=g).to(DEV)
+    want1 = A1.double().T @ B1.double()
+    h = cell[:, :, 2].double().view(nb, Tw, 50)
+    hprev = torch.zeros_like(h)
+    hprev[:, 1:] = h[:, :-1]
+    want2 = A2.double().T @ hprev.reshape(nb * Tw, 50)
+    want3 = A3.double().view(nb, Tw, 200)[:, :T].reshape(nb * T, 200).T @ B3.double()
+    probs = [(A1, K1, ptr(B1), 175, 1, 0, 0, 0, 0, 175, 256), (A2, nb * Tw, ptr(cell, 2), 200, 4, Tw, Tw, Tw, 1, 50, 96),
+             (A3, nb * T, ptr(B3), 175, 1, T, Tw, T, 0, 175, 64)]
+    arr = (S2GGemm * len(probs))()
+    outs, prefix, blocks = [], [], 0
+    for i, (A, K, Bp, sbk, sbn, segT, a_seg, b_seg, shift, N, kchunk) in enumerate(probs):
+        ns = (K + kchunk - 1) // kchunk
+        out = torch.full((ns, 200, N), float("nan"), device=DEV)
+        outs.append(out)
+        arr[i] = S2GGemm(ptr(A), 1, 200, Bp, sbk, sbn, ptr(out), N, 200 * N, None, 200, N, K, kchunk, segT, a_seg,
+                         b_seg, shift, 0, 0, 1.0)
+        prefix.append(blocks)
+        blocks += ns * ((N + 63) // 64)          # a workgroup owns all 200 rows of 64 columns over one K-chunk
+    prefix.append(blocks)
+    raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(DEV)
+    pre = torch.tensor(prefix, dtype=torch.int32, device=DEV)
+    call("s2g_gemm_grouped", ptr(raw), ptr(pre), len(probs), blocks, stream_ptr())
+    torch.cuda.synchronize()
+    for out, want in zip(outs, (want1, want2, want3)):
+        assert rel(out.double().sum(0), want) < 1e-5
+
+
 def test_dropout_mask_matches_torch():
     from s2g.lib import call
     from s2g.ops import ptr, stream_ptr

@@ -104,6 +104,39 @@ def main():
         tall["delta_w0"] = timeit(lambda: ops.gemm_tall(ptr(ws["delta0"], r0 * 200), 200, ptr(eng.W0p), eng.Vp,
                                                         ptr(G), V, B * T, V, 200))
         print("tall products:", " ".join(f"{k}={v:.1f}us" for k, v in tall.items()))
+    if "--wgrad" in sys.argv:
+        from s2g import critic as C
+        G4 = 200
+        d0, d1, c0, c1 = ws["delta0"].normal_(), ws["delta1"].normal_(), ws["cell0"].normal_(), ws["cell1"].normal_()
+        a0, a1 = ws["abar0"].normal_(), ws["abar1"].normal_()
+        x = torch.rand(B * T, V, device=dev)
+        n12, n3, oi = 2 * B * T, B * T, r0 * 200
+        gw = [torch.empty(200, n, device=dev) for n in (V, 50, 50, 50)]
+        for phases in ((2,), (1,), (0,), (3,)):
+            def tm(A, K, Bp, sbk, sbn, segT, shift, ph):
+                return (A, K, Bp, sbk, sbn, segT, segT, segT, shift, ph)
+            jobs = [(gw[0], V, []), (gw[1], 50, []), (gw[2], 50, []), (gw[3], 50, [])]
+            if 2 in phases:
+                jobs[0][2].append(tm(ptr(a0), n3, ptr(x), V, 1, T, False, 2))
+                jobs[1][2].append(tm(ptr(a0), n3, ptr(c0, oi + 2), G4, 4, T, True, 2))
+                jobs[2][2].append(tm(ptr(a1), n3, ptr(c0, oi + 3), G4, 4, 0, False, 2))
+                jobs[3][2].append(tm(ptr(a1), n3, ptr(c1, oi + 2), G4, 4, T, True, 2))
+            if 3 in phases:                     # the wide product alone
+                jobs[0][2].append(tm(ptr(a0), n3, ptr(x), V, 1, T, False, 3))
+            if 1 in phases:
+                jobs[1][2].append(tm(ptr(d0, oi), n3, ptr(c0, 1), G4, 4, T, True, 1))
+                jobs[2][2].append(tm(ptr(d1, oi), n3, ptr(c0, 2), G4, 4, 0, False, 1))
+                jobs[3][2].append(tm(ptr(d1, oi), n3, ptr(c1, 1), G4, 4, T, True, 1))
+            if 0 in phases:
+                for k in range(3):
+                    jobs[0][2].append(tm(ptr(d0, k * n3 * 200), n3, ptr(x), V, 1, T, False, 0))
+                jobs[1][2].append(tm(ptr(d0), n12, ptr(c0, 2), G4, 4, T, True, 0))
+                jobs[2][2].append(tm(ptr(d1), n12, ptr(c0, 3), G4, 4, 0, False, 0))
+                jobs[3][2].append(tm(ptr(d1), n12, ptr(c1, 2), G4, 4, T, True, 0))
+            built = C._wgrad_build(eng, jobs, ("bench", phases))
+            t = timeit(lambda: C._wgrad_launch(eng, built, phases[0]))
+            tr = timeit(lambda: C._wgrad_reduce(eng, built))
+            print(f"wgrad phase {phases[0]}: gemm {t:.1f}us blocks={built[0][phases[0]][3]} reduce {tr:.1f}us")
     print(f"T={T} per-step ns:", " ".join(f"{k}={v * 1e3 / (T + 2):.0f}" for k, v in res.items()))
     print(" ".join(f"{k}={v:.1f}us" for k, v in res.items()), f"sum4={res['fwd_192'] + res['bwd_192'] + res['tangent_64'] + res['bwd2_64']:.1f}us")
 
