@@ -124,9 +124,12 @@ def main():
 
     # per-kernel timing of the five heavy kernels of a critic iteration (the four LSTM sweeps and the
     # grouped weight-gradient GEMM): HIP events on the stream the kernels are launched on, recorded
-    # inside the timed region
+    # inside the timed region.  Every 6th critic iteration is bracketed (14 event records each), so the
+    # sampled position walks through the five iterations of a step: bracketing all of them costs 3-8 % of
+    # the step itself (7.39 against 7.14 ms at 10 steps, 7.84 against 7.17 ms at 20).
     ev = {}
     tr.D.timed_events = ev
+    tr.D.timed_every = 6
 
     def one_step(k):
         batches = [pool[(k * N_CRITIC + i) % len(pool)][:4] for i in range(N_CRITIC)]
@@ -159,7 +162,8 @@ def main():
 
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
-        seqs = N_CRITIC * B_PER_GPU * world * a.steps
+        print(f"[bench] {ms_per_step:.3f} ms/step, host enqueue {t_host / a.steps * 1e3:.3f} ms/step", file=sys.stderr)
+        seqs =N_CRITIC * B_PER_GPU * world * a.steps
         # algorithmic FLOP per launch (averaged over the batches of the pool)
         real = sum(int(p[2].sum()) for p in pool[:N_CRITIC]) / N_CRITIC      # live real steps per batch
         fake_steps = B_PER_GPU * GEN_SEQ_LEN

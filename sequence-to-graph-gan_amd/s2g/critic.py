@@ -64,6 +64,9 @@ class CriticEngine:
         self._scalars = {}
         self.scratch = ops.Scratch(device)
         self.timed_events = None      # dict kernel name -> [(start, end) HIP event pairs] (benchmark hook)
+        self.timed_every = 1          # ... filled for every n-th critic iteration only (event pairs are not free:
+        self._timed_iter = 0          # 14 per iteration cost ~3 % of the step and pile up in the runtime's pools)
+        self._timed_now = True
         self._gemm_tables = {}        # cached device-side problem tables of the grouped weight-gradient GEMM
         self._wgrad_slabs = None      # split-K slabs of the weight-gradient products
         self.overlap = True           # run the work that does not depend on sweeps C/D beside them (critic_iteration)
@@ -218,7 +221,7 @@ class CriticEngine:
         """Runs fn(); when the benchmark hook is set, brackets it with HIP events on the current stream
         (the one every libs2g launch of this engine goes to)."""
         te = self.timed_events
-        if te is None:
+        if te is None or not self._timed_now:
             fn()
             return
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -456,6 +459,8 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         raise S2GError("critic_iteration: batch size mismatch")
     Tw = max(T, Tf)
     ws = eng.workspace(3 * B, Tw, B)
+    eng._timed_iter += 1
+    eng._timed_now = eng._timed_iter % eng.timed_every == 0
     if mask is not None:
         ops._chk(mask, name="mask")
         if tuple(mask.shape) != (3 * B * Tw, MASKW):
