@@ -214,6 +214,7 @@ class CriticEngine:
             # implicitly with the NULL stream, torch's default.  The sweeps it must run beside are
             # therefore put on a third, non-blocking stream for the duration of the overlap.
             ev = [torch.cuda.Event() for _ in range(4)]      # fork, after sweep C, join (stream2), join (stream_c)
+            self._iter_events = (torch.cuda.Event(), torch.cuda.Event())   # small pieces done, after sweep D
             self._side = (stream, torch.cuda.Stream(device=self.device), *ev, ops.Scratch(self.device))
         return self._side or None
 
@@ -595,7 +596,7 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         # the small launch-bound pieces (loss values + fc gradients, first-order bias sums) go beside the
         # operand / product chain of stream2, which must be through before sweep D is
         small = eng.stream_g if eng.stream_g is not None else stream2
-        join_g = torch.cuda.Event()
+        join_g, after_d = eng._iter_events
         with torch.cuda.stream(small):
             small.wait_event(fork)
             head_losses()
@@ -620,7 +621,6 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
                 stream_c.wait_event(fork)
                 idle()
         with torch.cuda.stream(sweeps):
-            after_d = torch.cuda.Event()
             eng.timed("s2g_k_lstm2_bwd2", lambda: eng.sweep_bwd2(ws, drel, B, Tw, mrel, r_int, bsum=ws["bsumD"]))
             after_d.record()
         if idle is not None and not own:
@@ -628,8 +628,7 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         if not own:
             cur.wait_event(after_d)
         cur.wait_event(join)
-        cur.wait_event(join_g)
-        _wgrad_launch(eng, built, 2)
+        _wgrad_launch(eng, built, 2)          # (join_g is covered by join_c below: stream_c waits for it first)
         with torch.cuda.stream(stream_c):
             if own:
                 stream_c.wait_event(after_d)
