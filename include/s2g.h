@@ -85,6 +85,23 @@ typedef struct S2GReduce {
 } S2GReduce;
 int s2g_reduce_slabs_multi(const S2GReduce* jobs, int njobs, int permute_rows, int accumulate, float scale,
                            void* stream);
+/* one process only (no all-reduce between gradient and update): the final slab reduction of the four
+ * LSTM weight gradients (job[0..3] = W_ih0, W_hh0, W_ih1, W_hh1, as in s2g_reduce_slabs_multi with
+ * permute_rows), optimizer_D.step() (Adam, wgan_gp.py:318) on every critic parameter, and the packed
+ * copies of s2g_pack_critic, in ONE launch.  p/g/m/v: the flat parameter, gradient and moment buffers;
+ * poff / o_*: element offsets of the parameters in them; the gradients of the biases and the fc head
+ * are read from g, those of the four matrices are also written to job[k].out. */
+typedef struct S2GCriticUpdate {
+  S2GReduce job[4];
+  long poff[4];
+  float *p, *g, *m, *v;
+  long o_bih0, o_bhh0, o_bih1, o_bhh1, o_fcw, o_fcb;
+  int n_fcw, n_fcb, V, Vp;
+  float *WT0, *W0p, *b0, *b1;
+  float lr, b1, b2, eps;
+  int step;
+} S2GCriticUpdate;
+int s2g_critic_update(const S2GCriticUpdate* u, void* stream);
 /* part[chunk][c] = sum over a chunk of rows of X[r*ld + c]; nchunk = ceil(rows / rows_per_chunk). */
 int s2g_colsum(const float* X, long ld, long rows, int cols, float* part, long rows_per_chunk, void* stream);
 /* bias gradients of the two LSTM layers (what backward() accumulates into lstm.bias_ih/_hh_l{0,1},

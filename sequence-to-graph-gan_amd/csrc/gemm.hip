@@ -465,6 +465,77 @@ extern "C" __global__ __launch_bounds__(256) void s2g_k_reduce_slabs_multi(Reduc
                      blockIdx.x - q.first_block);
 }
 
+// The critic's whole parameter update in one launch (one process: no all-reduce between the gradient
+// and Adam): the final slab reduction of the four LSTM weight gradients (same blocks and order of
+// additions as s2g_k_reduce_slabs_multi, gradient written in torch layout as before), Adam on the
+// element just reduced (the expression of s2g_k_adam), and the packed copies the sweeps read
+// (s2g_k_pack_critic: WT0 / W0p for W_ih0, b0 / b1 = b_ih + b_hh).  Blocks from tail_block on update the
+// parameters whose gradients other kernels left in g: one thread per gate row does b_ih and b_hh of a
+// layer and their sum, the rest take the fc head.
+struct CriticUpdate {
+  ReduceJob j[4];            // W_ih0, W_hh0, W_ih1, W_hh1 (out = gradient view, first_block as in ReduceJobs)
+  long poff[4];              // offset of the job's parameter in the flat buffers
+  float *p, *g, *m, *v;      // flat parameter / gradient / Adam moment buffers
+  long o_bih0, o_bhh0, o_bih1, o_bhh1, o_fcw, o_fcb;
+  int n_fcw, n_fcb, tail_block, V, Vp;
+  float *WT0, *W0p, *b0, *b1;
+  float b1c, b2c, eps, step_size, inv_sqrt_bc2;
+};
+__device__ __forceinline__ float adam_one(const CriticUpdate& a, long o, float gg) {
+  const float mm = a.b1c * a.m[o] + (1.0f - a.b1c) * gg;
+  const float vv = a.b2c * a.v[o] + (1.0f - a.b2c) * gg * gg;
+  const float pn = a.p[o] - a.step_size * (mm / (sqrtf(vv) * a.inv_sqrt_bc2 + a.eps));
+  a.m[o] = mm; a.v[o] = vv; a.p[o] = pn;
+  return pn;
+}
+extern "C" __global__ __launch_bounds__(256) void s2g_k_critic_update(CriticUpdate a) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if ((int)blockIdx.x >= a.tail_block) {
+    const int t = ((int)blockIdx.x - a.tail_block) * 256 + threadIdx.x;
+    if (t < 2 * S2G_G) {
+      const int layer = t / S2G_G, jr = t % S2G_G, o = pt_row(jr);
+      const long oi = (layer ? a.o_bih1 : a.o_bih0) + o, oh = (layer ? a.o_bhh1 : a.o_bhh0) + o;
+      const float bi = adam_one(a, oi, a.g[oi]);
+      const float bh = adam_one(a, oh, a.g[oh]);
+      (layer ? a.b1 : a.b0)[jr] = bi + bh;
+    } else if (t < 2 * S2G_G + a.n_fcw) {
+      const long o = a.o_fcw + (t - 2 * S2G_G);
+      adam_one(a, o, a.g[o]);
+    } else if (t < 2 * S2G_G + a.n_fcw + a.n_fcb) {
+      const long o = a.o_fcb + (t - 2 * S2G_G - a.n_fcw);
+      adam_one(a, o, a.g[o]);
+    }
+    return;
+  }
+  int k = 0;
+  while (k + 1 < 4 && (int)blockIdx.x >= a.j[k + 1].first_block) ++k;
+  const ReduceJob& q = a.j[k];
+  const long i = (long)((int)blockIdx.x - q.first_block) * 64 + lane;
+  const bool ok = i < (long)q.rows * q.cols;
+  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+  if (ok) {
+    int z = w;
+    for (; z + 12 < q.nslab; z += 16) {
+      s0 += q.slabs[(long)z * q.slab + i]; s1 += q.slabs[(long)(z + 4) * q.slab + i];
+      s2 += q.slabs[(long)(z + 8) * q.slab + i]; s3 += q.slabs[(long)(z + 12) * q.slab + i];
+    }
+    for (; z < q.nslab; z += 4) s0 += q.slabs[(long)z * q.slab + i];
+  }
+  red[w][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (w != 0 || !ok) return;
+  const float s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  const int r = (int)(i / q.cols), c = (int)(i % q.cols);
+  const long o = (long)pt_row(r) * q.cols + c;
+  q.out[o] = s;
+  const float pn = adam_one(a, a.poff[k] + o, s);
+  if (k == 0) {
+    a.W0p[(long)r * a.Vp + c] = pn;
+    a.WT0[(long)c * S2G_G + r] = pn;
+  }
+}
+
 // column sums: out[perm(c)] (+)= scale * sum_r X[r][c], X row-major [rows, cols] with row stride ld.
 // grid = (ceil(cols/64), nchunk); partial sums land in `part[chunk][cols]`, reduced by
 // s2g_k_reduce_slabs with rows = 1.
@@ -743,5 +814,10 @@ extern "C" int s2g_launch_gemm(const GemmArgs* ga, int nsplit, hipStream_t strea
 extern "C" int s2g_launch_gemm_grouped(const GemmArgs* table_dev, const int* prefix_dev, int nprob, int total_blocks,
                                        hipStream_t stream) {
   hipLaunchKernelGGL(s2g_k_gemm_grouped, dim3(total_blocks), dim3(256), 0, stream, table_dev, prefix_dev, nprob);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int s2g_launch_critic_update(const CriticUpdate* a, int blocks, hipStream_t stream) {
+  hipLaunchKernelGGL(s2g_k_critic_update, dim3(blocks), dim3(256), 0, stream, *a);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

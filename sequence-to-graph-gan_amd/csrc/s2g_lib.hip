@@ -90,6 +90,42 @@ int s2g_reduce_slabs_multi(const S2GReduce* jobs, int njobs, int permute_rows, i
                      scale);
   return LAUNCH_OK();
 }
+struct S2GCriticUpdate {
+  S2GReduce job[4];
+  long poff[4];
+  float *p, *g, *m, *v;
+  long o_bih0, o_bhh0, o_bih1, o_bhh1, o_fcw, o_fcb;
+  int n_fcw, n_fcb, V, Vp;
+  float *WT0, *W0p, *b0, *b1;
+  float lr, b1c, b2c, eps;
+  int step;
+};
+int s2g_critic_update(const S2GCriticUpdate* u, void* stream) {
+  if (!u || !u->p || !u->g || !u->m || !u->v || !u->WT0 || !u->W0p || !u->b0 || !u->b1 || u->step < 1) return -1;
+  if (u->V <= 0 || u->Vp < u->V || u->n_fcw < 0 || u->n_fcb < 0) return -1;
+  CriticUpdate a;
+  int blocks = 0;
+  for (int k = 0; k < 4; ++k) {
+    const S2GReduce& q = u->job[k];
+    if (!q.slabs || !q.out || q.nslab <= 0 || q.rows != S2G_G || q.cols <= 0 || u->poff[k] < 0) return -1;
+    a.j[k] = ReduceJob{q.slabs, q.slab, q.out, q.nslab, q.rows, q.cols, blocks};
+    a.poff[k] = u->poff[k];
+    blocks += (int)cdiv((long)q.rows * q.cols, 64);
+  }
+  if (u->job[0].cols != u->V) return -1;
+  a.p = u->p; a.g = u->g; a.m = u->m; a.v = u->v;
+  a.o_bih0 = u->o_bih0; a.o_bhh0 = u->o_bhh0; a.o_bih1 = u->o_bih1; a.o_bhh1 = u->o_bhh1;
+  a.o_fcw = u->o_fcw; a.o_fcb = u->o_fcb; a.n_fcw = u->n_fcw; a.n_fcb = u->n_fcb;
+  a.tail_block = blocks; a.V = u->V; a.Vp = u->Vp;
+  a.WT0 = u->WT0; a.W0p = u->W0p; a.b0 = u->b0; a.b1 = u->b1;
+  const double bc1 = 1.0 - pow((double)u->b1c, (double)u->step);
+  const double bc2 = 1.0 - pow((double)u->b2c, (double)u->step);
+  a.b1c = u->b1c; a.b2c = u->b2c; a.eps = u->eps;
+  a.step_size = (float)((double)u->lr / bc1);
+  a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  blocks += (int)cdiv(2 * S2G_G + u->n_fcw + u->n_fcb, 256);
+  return s2g_launch_critic_update(&a, blocks, ST(stream));
+}
 int s2g_colsum(const float* X, long ld, long rows, int cols, float* part, long rows_per_chunk, void* stream) {
   if (!X || !part || rows <= 0 || cols <= 0 || rows_per_chunk <= 0) return -1;
   hipLaunchKernelGGL(s2g_k_colsum, dim3(cdiv(cols, 64), cdiv(rows, rows_per_chunk)), dim3(256), 0, ST(stream), X,

@@ -69,6 +69,7 @@ class CriticEngine:
         self._timed_now = True
         self._gemm_tables = {}        # cached device-side problem tables of the grouped weight-gradient GEMM
         self._wgrad_slabs = None      # split-K slabs of the weight-gradient products
+        self._pending_built = None    # weight-gradient plan whose final reduce was left to fused_update
         self.overlap = True           # run the work that does not depend on sweeps C/D beside them (critic_iteration)
         self._side = None             # (stream, fork event, join event, scratch) of that second stream
         self.stream_g = None          # CU-masked stream of the prefetch hook (created with _side)
@@ -83,11 +84,43 @@ class CriticEngine:
             v.copy_(state[k].to(self.device, torch.float32))
         self.repack()
 
-    def repack(self) -> None:
+    def fused_update(self, m: torch.Tensor, v: torch.Tensor, lr: float, b1: float, b2: float, eps: float,
+                     step: int) -> None:
+        """optimizer_D.step() (wgan_gp.py:318) for one process, straight from the split-K slabs a
+        critic_iteration(defer_reduce=True) left behind: final slab reduction (the gradients still land in
+        self.grads), Adam on every parameter and the packed copies of repack() in one launch; then M2."""
+        from .lib import S2GCriticUpdate, S2GReduce
+        built, self._pending_built = self._pending_built, None
+        if built is None:
+            raise S2GError("fused_update: no critic_iteration(defer_reduce=True) pending")
+        _, job_slabs, slabs = built
+        names = ("lstm.weight_ih_l0", "lstm.weight_hh_l0", "lstm.weight_ih_l1", "lstm.weight_hh_l1")
+        off = self.params.offsets
+        u = S2GCriticUpdate()
+        for k, (name, (out, n_early, n_late, slab, base)) in enumerate(zip(names, job_slabs)):
+            if out.data_ptr() != self.grads.views[name].data_ptr() or n_early + n_late == 0:
+                raise S2GError("fused_update: unexpected weight-gradient jobs")
+            first = base + n_early * slab if n_early else base
+            u.job[k] = S2GReduce(ptr(slabs, first), slab, ptr(out), (1 if n_early else 0) + n_late, G4, slab // G4)
+            u.poff[k] = off[name][0]
+        u.p, u.g, u.m, u.v = ptr(self.params.flat), ptr(self.grads.flat), ptr(m), ptr(v)
+        u.o_bih0, u.o_bhh0 = off["lstm.bias_ih_l0"][0], off["lstm.bias_hh_l0"][0]
+        u.o_bih1, u.o_bhh1 = off["lstm.bias_ih_l1"][0], off["lstm.bias_hh_l1"][0]
+        u.o_fcw, u.o_fcb = off["fc.weight"][0], off["fc.bias"][0]
+        u.n_fcw, u.n_fcb = off["fc.weight"][1], off["fc.bias"][1]
+        u.V, u.Vp = self.V, self.Vp
+        u.WT0, u.W0p, u.b0, u.b1 = ptr(self.WT0), ptr(self.W0p), ptr(self.b0), ptr(self.b1)
+        u.lr, u.b1c, u.b2c, u.eps, u.step = lr, b1, b2, eps, step
+        call("s2g_critic_update", ctypes.byref(u), stream_ptr())
+        self.repack(packed=True)
+
+    def repack(self, packed: bool = False) -> None:
+        """packed: WT0 / W0p / b0 / b1 are already current (fused_update wrote them); only M2 is rebuilt."""
         p = self.params.views
-        call("s2g_pack_critic", ptr(p["lstm.weight_ih_l0"]), ptr(p["lstm.bias_ih_l0"]), ptr(p["lstm.bias_hh_l0"]),
-             ptr(p["lstm.bias_ih_l1"]), ptr(p["lstm.bias_hh_l1"]), ptr(self.WT0), ptr(self.W0p), ptr(self.b0),
-             ptr(self.b1), self.V, stream_ptr())
+        if not packed:
+            call("s2g_pack_critic", ptr(p["lstm.weight_ih_l0"]), ptr(p["lstm.bias_ih_l0"]), ptr(p["lstm.bias_hh_l0"]),
+                 ptr(p["lstm.bias_ih_l1"]), ptr(p["lstm.bias_hh_l1"]), ptr(self.WT0), ptr(self.W0p), ptr(self.b0),
+                 ptr(self.b1), self.V, stream_ptr())
         # M2 = W_ih0 W_ih0^T (internal gate order): maps layer-0 gate gradients straight to the projected
         # input gradient (critic_iteration).  Its first reader comes after sweeps A and B of the next
         # iteration, so with the side streams up it is built there, off the caller's stream.
@@ -434,7 +467,7 @@ def _wgrad_grouped(eng: "CriticEngine", jobs, cache_key) -> None:
 def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Tensor, labels: torch.Tensor,
                      fake: torch.Tensor, alpha: torch.Tensor, lambda_gp: float, n_global: int, inv_wsum: float,
                      mask: Optional[torch.Tensor] = None, class_w=(1.0, 2.0), prefetch=None, idle=None,
-                     desc: Optional[torch.Tensor] = None):
+                     desc: Optional[torch.Tensor] = None, defer_reduce: bool = False):
     """One critic loss + gradient evaluation (wgan_gp.py:297-317) on the batch
     [real B | fake B | interp B], all three passes sharing each of the four sweeps.
 
@@ -442,6 +475,8 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
     (the trainer generates the next iteration's fake batch in it); it is NOT waited for here, the
     caller synchronises with whatever it enqueued.
     desc: optional descriptors prepared with batch_desc for exactly these lengths / alpha / T / Tf / mask.
+    defer_reduce: leave the final slab reduction of the four LSTM weight gradients to
+    CriticEngine.fused_update (those four gradients are then NOT yet in eng.grads on return).
     idle: optional callable run on the caller's stream while it would otherwise wait for the
     second-order sweeps (the trainer draws the next iteration's noise and dropout mask in it).
 
@@ -635,7 +670,8 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
             stream_c.wait_event(join_g)      # the first-order bias sums and fc gradients these accumulate onto
             second_order_sums()
             join_c.record()
-        _wgrad_reduce(eng, built)
+        if not defer_reduce:
+            _wgrad_reduce(eng, built)
         cur.wait_event(join_c)
     else:
         eng.timed("s2g_k_lstm2_tangent", lambda: eng.sweep_tangent(ws, drel, B, mrel, r_int, gp))
@@ -648,10 +684,12 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         if prefetch is not None:
             prefetch()
         _wgrad_launch(eng, built, 2)
-        _wgrad_reduce(eng, built)
+        if not defer_reduce:
+            _wgrad_reduce(eng, built)
         second_order_sums()
         if idle is not None:
             idle()
+    eng._pending_built = built if defer_reduce else None
     return ws["losses"], ws["pen"]
 
 

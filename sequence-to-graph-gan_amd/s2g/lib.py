@@ -38,6 +38,13 @@ class S2GReduce(ctypes.Structure):
     _fields_ = [("slabs", P), ("slab", L), ("out", P), ("nslab", I), ("rows", I), ("cols", I)]
 
 
+class S2GCriticUpdate(ctypes.Structure):
+    _fields_ = [("job", S2GReduce * 4), ("poff", L * 4), ("p", P), ("g", P), ("m", P), ("v", P),
+                ("o_bih0", L), ("o_bhh0", L), ("o_bih1", L), ("o_bhh1", L), ("o_fcw", L), ("o_fcb", L),
+                ("n_fcw", I), ("n_fcb", I), ("V", I), ("Vp", I), ("WT0", P), ("W0p", P), ("b0", P), ("b1", P),
+                ("lr", F), ("b1c", F), ("b2c", F), ("eps", F), ("step", I)]
+
+
 # name -> argument types (every function returns int and takes the stream last)
 SIGNATURES = {
     "s2g_version": [],
@@ -47,6 +54,7 @@ SIGNATURES = {
     "s2g_gemm_f32": [ctypes.POINTER(S2GGemm), I, P],
     "s2g_gemm_tall": [P, L, P, L, P, L, I, I, I, P],
     "s2g_gemm_grouped": [P, P, I, I, P],
+    "s2g_critic_update": [ctypes.POINTER(S2GCriticUpdate), P],
     "s2g_reduce_slabs": [P, L, I, I, I, P, I, I, F, P],
     "s2g_reduce_slabs_multi": [P, I, I, I, F, P],
     "s2g_colsum": [P, L, L, I, P, L, P],

@@ -59,6 +59,7 @@ class WGANGPTrainer:
         self._prefetched = None       # dict(z, labels, done event) of the fake batch the last critic_step prepared
         self._gen_prefetched = None   # dict(z, labels, U, fake, done event) of a generator forward made ahead
         self._stream = None           # non-blocking stream full_step runs on (see full_step)
+        self.fuse_update = True       # critic update as one launch when there is no all-reduce to wait for
         self._g_pending = None        # (done event, tensors kept alive) of a generator update on the side stream
         self._desc = [None, None]     # descriptor buffers of the batch in flight and of the next one
         self._desc_cur = 0
@@ -191,9 +192,11 @@ class WGANGPTrainer:
                     gp["mask"] = dropout_mask(B * self.L, self.drop_rate, dev)
         else:
             idle = None
+        # one process: the final slab reduction, Adam and the weight repack run as one launch
+        fused = update and self.fuse_update and self.comm.world == 1
         losses, pen = critic_iteration(self.D, tokens, lengths, labels, fake, alpha.reshape(-1).contiguous(),
                                        self.lambda_gp, n_global, 1.0 / wsum, mask, CLASS_W, prefetch=prefetch,
-                                       idle=idle, desc=desc)
+                                       idle=idle, desc=desc, defer_reduce=fused)
         if prefetch is not None and next_batch is not None:
             self._prefetched = nxt
             self._fake_cur ^= 1
@@ -201,8 +204,11 @@ class WGANGPTrainer:
             self._gen_prefetched = gp
         if update:
             self.tD += 1
-            self._adam(self.D, self.mD, self.vD, self.tD)
-            self.D.repack()
+            if fused:
+                self.D.fused_update(self.mD, self.vD, self.lr, self.b1, self.b2, self.eps, self.tD)
+            else:
+                self._adam(self.D, self.mD, self.vD, self.tD)
+                self.D.repack()
         self.last = dict(z=z, labels=labels, d_parts=losses, pen=pen, n_global=n_global, wsum=wsum)
         return losses, pen
 

@@ -204,3 +204,35 @@ def test_full_step_streams_and_prefetch_are_bit_exact():
     for b, v in serial.G.buffers.items():
         assert torch.equal(v, fused.G.buffers[b]), b
     assert torch.equal(serial.last["d_parts"], fused.last["d_parts"])
+
+
+def test_fused_critic_update_matches_reduce_adam_repack():
+    """The one-launch critic update (final slab reduction + Adam + packed weight copies) against the
+    same update as three launches (s2g_reduce_slabs_multi, s2g_adam, s2g_pack_critic): gradients,
+    parameters, Adam moments and the packed copies after three critic updates."""
+    from s2g.trainer import WGANGPTrainer
+    Tf, B, T = 24, 8, 32
+    pg, pd = common.generator_params(951, 175, Tf), common.critic_params(952, scale=1.5)
+    batches = [dev_batch(*common.batch(960 + i, B, T, min_len=3)) for i in range(3)]
+    noises = []
+    for i in range(3):
+        nz = {n: v.to(DEV) for n, v in common.noise(970 + i, B, Tf).items()}
+        nz["alpha"] = nz["alpha"].view(-1).contiguous()
+        noises.append(nz)
+    trs = []
+    for fuse in (False, True):
+        tr = WGANGPTrainer(175, Tf, DEV, drop_rate=0.0)
+        tr.G.load(pg); tr.D.load(pd)
+        tr.fuse_update = fuse
+        for (tok, lab, ln, wsum), nz in zip(batches, noises):
+            tr.critic_step(tok, lab, ln, wsum, nz["z"], nz["U"], nz["alpha"], None)
+        torch.cuda.synchronize()
+        trs.append(tr)
+    a, b = trs
+    # (not bit for bit: the compiler contracts the Adam expression differently in the two kernels, and
+    # from the second update on the gradients see parameters that differ in the last place)
+    for name, x, y in (("gradients", a.D.grads.flat, b.D.grads.flat), ("params", a.D.params.flat, b.D.params.flat),
+                       ("m", a.mD, b.mD), ("v", a.vD, b.vD),
+                       ("WT0", a.D.WT0, b.D.WT0), ("W0p", a.D.W0p, b.D.W0p), ("b0", a.D.b0, b.D.b0),
+                       ("b1", a.D.b1, b.D.b1), ("M2", a.D.m2(), b.D.m2())):
+        assert_close(y, x, 1e-5, name)
