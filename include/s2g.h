@@ -71,7 +71,7 @@ int s2g_gemm_f32(const S2GGemm* args, int nsplit, void* stream);
 int s2g_gemm_tall(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N, int K,
                   void* stream);
 /* nprob problems in ONE launch.  table_dev / prefix_dev are DEVICE arrays: S2GGemm[nprob] (every
- * problem of the weight-gradient shape: A = [rows, M] with sam == 1, M % 4 == 0, M <= 256,
+ * problem of the weight-gradient shape: A = [rows, M] with sam == 1, M % 4 == 0, M <= 208,
  * sak % 4 == 0 and a 16-byte aligned base, kchunk > 0 set by the caller, no bias / act /
  * accumulate) and int[nprob + 1] block prefix sums; problem p owns ceil(N/64) * nsplit_p blocks,
  * each computing all M rows of 64 columns over one K-chunk. */

@@ -257,16 +257,17 @@ __global__ __launch_bounds__(256) void s2g_k_gemm_f32(GemmArgs g) {
   gemm_tile<AMODE, BMODE>(g, blockIdx.x, blockIdx.y, blockIdx.z, As, Bs);
 }
 
-// Weight-gradient tile (TN shape, K = all saved rows): C[0:256, n0:n0+64] over one K-slab, M <= 256.
+// Weight-gradient tile (TN shape, K = all saved rows): C[0:M, n0:n0+64] over one K-slab, M <= 208.
 // A = [rows, M] row-major with sam == 1 and M % 4 == 0, B generic strides.
 // Loader: wave w fetches rows k0 + w + 4e (e = 0..7) of both operands, one row per load
 // instruction with the lanes along m (float4) / n, so the row index -- and with it the whole
 // (sequence, step) bookkeeping of the segT mapping and the row address -- is wave-uniform and
 // lives in scalar registers; the vector unit only adds a constant lane offset.
-// MFMA: wave w owns rows [64w, 64w+64) x all 64 columns = four 32x32 accumulators; per k-pair it
-// reads 2 A and 2 B fragments for 4 MFMAs.
-#define WBM 256
-#define WLD_A 260   // k-major A tile [BK][256 + 4]
+// MFMA (v_mfma_f32_16x16x4_f32): wave w owns columns [16w, 16w+16) x all 13 row tiles, so the 200 rows
+// are padded to 208 (not 256) and the four waves carry the same load.
+#define WG_MT 13     // 16-row tiles: M <= 208
+#define WLD_A 272   // k-major A tile [BK][256 + 16]: = 16 mod 64 floats, conflict-free 16x4 fragment reads
+#define WLD_B 80    // k-major B tile [BK][64 + 16]
 __device__ __forceinline__ void wgrad_tile(const GemmArgs& g, const int bx, const int bz, float* As, float* Bs) {
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -325,15 +326,19 @@ __device__ __forceinline__ void wgrad_tile(const GemmArgs& g, const int bx, cons
       float4 v;
       v.x = la ? ra[e].x : 0.0f; v.y = la ? ra[e].y : 0.0f; v.z = la ? ra[e].z : 0.0f; v.w = la ? ra[e].w : 0.0f;
       *reinterpret_cast<float4*>(As + kr * WLD_A + 4 * lane) = v;
-      Bs[kr * LDS_LD + lane] = lb ? rbv[e] : 0.0f;
+      Bs[kr * WLD_B + lane] = lb ? rbv[e] : 0.0f;
     }
   };
 
-  f32x16 acc00, acc01, acc10, acc11;
+  // wave w owns column tile w (16 columns) x all 13 row tiles (208 rows): per k-quad 13 A fragments and one
+  // B fragment feed 13 MFMAs; fragments are double-buffered in registers (reads of quad q+1 before the
+  // MFMAs of quad q)
+  f32x4 acc[WG_MT];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { acc00[i] = 0.0f; acc01[i] = 0.0f; acc10[i] = 0.0f; acc11[i] = 0.0f; }
-  const int aoff = (lane >> 5) * WLD_A + wave * 64 + (lane & 31);
-  const int boff = (lane >> 5) * LDS_LD + (lane & 31);
+  for (int i = 0; i < WG_MT; ++i) acc[i] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+  const int aoff = (lane >> 4) * WLD_A + (lane & 15);
+  const int boff = (lane >> 4) * WLD_B + 16 * wave + (lane & 15);
+  const bool wave_live = n0 + 16 * wave < g.N;      // a column tile past N: nothing to multiply or store
 
   if (kbeg < kend) {
 #pragma unroll
@@ -344,17 +349,30 @@ __device__ __forceinline__ void wgrad_tile(const GemmArgs& g, const int bx, cons
       // The wave issues in order, so the next K-block's 8 row fetches (and their scalar
       // bookkeeping) are spread between the MFMAs instead of running before them with the matrix
       // pipe idle.  Past the last K-block they read element 0 and are discarded.
+      float fa[2][WG_MT], fb[2];
+      auto frag = [&](int q, float (&a)[WG_MT], float& bq) {
 #pragma unroll
-      for (int kk = 0; kk < BK; kk += 2) {
-        if (kk < 16) fetch(kk >> 1);          // first half of the loop: the rows land before the LDS store
-        const float a0 = As[aoff + kk * WLD_A];
-        const float a1 = As[aoff + 32 + kk * WLD_A];
-        const float b0 = Bs[boff + kk * LDS_LD];
-        const float b1 = Bs[boff + 32 + kk * LDS_LD];
-        acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
-        acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
-        acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
-        acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
+        for (int i = 0; i < WG_MT; ++i) a[i] = As[aoff + 4 * q * WLD_A + 16 * i];
+        bq = Bs[boff + 4 * q * WLD_B];
+      };
+      auto mma = [&](const float (&a)[WG_MT], float bq) {
+#pragma unroll
+        for (int i = 0; i < WG_MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bq, acc[i], 0, 0, 0);
+      };
+      if (wave_live) frag(0, fa[0], fb[0]);
+#pragma unroll
+      for (int q = 0; q < 8; q += 2) {
+        fetch(q); fetch(q + 1);
+        if (wave_live) {
+          frag(q + 1, fa[1], fb[1]);
+          __builtin_amdgcn_sched_barrier(0);      // keep the reads ahead of the MFMAs they do not feed
+          mma(fa[0], fb[0]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (q + 2 < 8) frag(q + 2, fa[0], fb[0]);
+          __builtin_amdgcn_sched_barrier(0);
+          mma(fa[1], fb[1]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
       __syncthreads();
       if (k0 + BK < kend) {
@@ -364,32 +382,31 @@ __device__ __forceinline__ void wgrad_tile(const GemmArgs& g, const int bx, cons
     }
   }
 
+  if (!wave_live) return;
   float* C = g.C + (long)bz * g.slab;
-  const int col = n0 + (lane & 31);
+  const int col = n0 + 16 * wave + (lane & 15);
+  if (col < g.N) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = wave * 64 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    if (row < g.M) {
-      if (col < g.N) C[(long)row * g.ldc + col] = g.alpha * acc00[r];
-      if (col + 32 < g.N) C[(long)row * g.ldc + col + 32] = g.alpha * acc01[r];
-    }
-    if (row + 32 < g.M) {
-      if (col < g.N) C[(long)(row + 32) * g.ldc + col] = g.alpha * acc10[r];
-      if (col + 32 < g.N) C[(long)(row + 32) * g.ldc + col + 32] = g.alpha * acc11[r];
+    for (int i = 0; i < WG_MT; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * i + 4 * (lane >> 4) + r;
+        if (row < g.M) C[(long)row * g.ldc + col] = g.alpha * acc[i][r];
+      }
     }
   }
 }
 
 // Grouped launch: `table` holds nprob independent problems, all of the TN weight-gradient shape:
 // A = [rows, M] row-major with sam == 1, sak % 4 == 0 and a 16-byte aligned base (loaded with
-// float4 along m), M % 4 == 0 and M <= 256, B with arbitrary strides, no bias / activation /
+// float4 along m), M % 4 == 0 and M <= 208, B with arbitrary strides, no bias / activation /
 // accumulate; problem p owns blocks [prefix[p], prefix[p+1]) of (all M) x 64 output tiles, ordered
 // (z, x) with x fastest.  One launch fills the chip with work that would otherwise be a dozen
 // small back-to-back launches.
 extern "C" __global__ __launch_bounds__(256) void s2g_k_gemm_grouped(const GemmArgs* __restrict__ table,
                                                                      const int* __restrict__ prefix, int nprob) {
   __shared__ __attribute__((aligned(16))) float As[BK * WLD_A];
-  __shared__ __attribute__((aligned(16))) float Bs[BK * LDS_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * WLD_B];
   // Workgroups are dealt round-robin to the 8 XCDs (id % 8), each with its own L2.  Remap so that
   // XCD x works through one contiguous range of logical blocks: the output tiles of one K-slab
   // (which share that slab's rows of A and B) then run back to back on one L2.
