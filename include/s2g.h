@@ -74,8 +74,12 @@ int s2g_gemm_tall(const float* A, long lda, const float* B, long ldb, float* C, 
  * problem of the weight-gradient shape: A = [rows, M] with sam == 1, M % 4 == 0, M <= 208,
  * sak % 4 == 0 and a 16-byte aligned base, kchunk > 0 set by the caller, no bias / act /
  * accumulate) and int[nprob + 1] block prefix sums; problem p owns ceil(N/64) * nsplit_p blocks,
- * each computing all M rows of 64 columns over one K-chunk. */
-int s2g_gemm_grouped(const S2GGemm* table_dev, const int* prefix_dev, int nprob, int total_blocks, void* stream);
+ * each computing all M rows of 64 columns over one K-chunk.
+ * nz > 0: every problem has exactly nz K-chunks and prefix_dev holds prefix sums of ceil(N/64), the
+ * output tiles per problem; blocks are then ordered K-chunk first (total_blocks = nz * prefix[nprob]), so
+ * problems that read the same rows of an operand find them in L2. */
+int s2g_gemm_grouped(const S2GGemm* table_dev, const int* prefix_dev, int nprob, int total_blocks, int nz,
+                     void* stream);
 int s2g_reduce_slabs(const float* slabs, long slab, int nslab, int rows, int cols, float* out,
                      int permute_rows, int accumulate, float scale, void* stream);
 /* up to 8 such reductions in one launch; `jobs` is a HOST array (copied into the kernel arguments) */

@@ -404,7 +404,8 @@ __device__ __forceinline__ void wgrad_tile(const GemmArgs& g, const int bx, cons
 // (z, x) with x fastest.  One launch fills the chip with work that would otherwise be a dozen
 // small back-to-back launches.
 extern "C" __global__ __launch_bounds__(256) void s2g_k_gemm_grouped(const GemmArgs* __restrict__ table,
-                                                                     const int* __restrict__ prefix, int nprob) {
+                                                                     const int* __restrict__ prefix, int nprob,
+                                                                     int nz) {
   __shared__ __attribute__((aligned(16))) float As[BK * WLD_A];
   __shared__ __attribute__((aligned(16))) float Bs[BK * WLD_B];
   // Workgroups are dealt round-robin to the 8 XCDs (id % 8), each with its own L2.  Remap so that
@@ -416,6 +417,18 @@ extern "C" __global__ __launch_bounds__(256) void s2g_k_gemm_grouped(const GemmA
   // every thread walks the (uniform) prefix table, so the problem descriptor arrives by scalar
   // loads and its fields stay in scalar registers
   int p = 0;
+  if (nz > 0) {
+    // Interleaved order (every problem has nz K-chunks; prefix counts OUTPUT TILES): all tiles of all
+    // problems for K-chunk z are neighbours, so products that share an operand (dW_ih0 and dW_hh0 read
+    // the same gate-gradient rows, dW_ih1 and dW_hh1 likewise) meet those rows in L2 instead of
+    // fetching them from HBM once per product.
+    const int tiles = prefix[nprob];
+    const int bz = lid / tiles, t = lid - bz * tiles;
+    while (p + 1 < nprob && t >= prefix[p + 1]) ++p;
+    const GemmArgs gs = table[p];
+    wgrad_tile(gs, t - prefix[p], bz, As, Bs);
+    return;
+  }
   while (p + 1 < nprob && lid >= prefix[p + 1]) ++p;
   const GemmArgs gs = table[p];
   const int local = lid - prefix[p];
@@ -829,8 +842,8 @@ extern "C" int s2g_launch_gemm(const GemmArgs* ga, int nsplit, hipStream_t strea
 }
 
 extern "C" int s2g_launch_gemm_grouped(const GemmArgs* table_dev, const int* prefix_dev, int nprob, int total_blocks,
-                                       hipStream_t stream) {
-  hipLaunchKernelGGL(s2g_k_gemm_grouped, dim3(total_blocks), dim3(256), 0, stream, table_dev, prefix_dev, nprob);
+                                       int nz, hipStream_t stream) {
+  hipLaunchKernelGGL(s2g_k_gemm_grouped, dim3(total_blocks), dim3(256), 0, stream, table_dev, prefix_dev, nprob, nz);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

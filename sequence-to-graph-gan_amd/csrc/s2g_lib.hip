@@ -55,9 +55,11 @@ int s2g_gemm_tall(const float* A, long lda, const float* B, long ldb, float* C, 
   return s2g_launch_gemm_tall(A, lda, B, ldb, C, ldc, M, N, K, ST(stream));
 }
 
-int s2g_gemm_grouped(const GemmArgs* table_dev, const int* prefix_dev, int nprob, int total_blocks, void* stream) {
-  if (!table_dev || !prefix_dev || nprob <= 0 || nprob > 64 || total_blocks <= 0) return -1;
-  return s2g_launch_gemm_grouped(table_dev, prefix_dev, nprob, total_blocks, ST(stream));
+int s2g_gemm_grouped(const GemmArgs* table_dev, const int* prefix_dev, int nprob, int total_blocks, int nz,
+                     void* stream) {
+  if (!table_dev || !prefix_dev || nprob <= 0 || nprob > 64 || total_blocks <= 0 || nz < 0) return -1;
+  if (nz > 0 && total_blocks % nz) return -1;
+  return s2g_launch_gemm_grouped(table_dev, prefix_dev, nprob, total_blocks, nz, ST(stream));
 }
 
 int s2g_reduce_slabs(const float* slabs, long slab, int nslab, int rows, int cols, float* out, int permute_rows,

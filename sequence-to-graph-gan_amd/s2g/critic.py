@@ -385,6 +385,7 @@ def _wgrad_build(eng: "CriticEngine", jobs, cache_key):
             c = chunk[phase]
             ns = max(1, min(256, (K + c // 2) // c))
             kchunk = ((K + ns - 1) // ns + 31) // 32 * 32
+            ns = (K + kchunk - 1) // kchunk
             (late if phase == last else early).append((phase, A, K, B, sbk, sbn, segT, a_seg, b_seg, shift, N, kchunk, ns))
         n_early = sum(e[-1] for e in early)
         n_late = sum(e[-1] for e in late)
@@ -411,15 +412,21 @@ def _wgrad_build(eng: "CriticEngine", jobs, cache_key):
             sel = [e for e in plan if e[0] == ph]
             arr = (S2GGemm * len(sel))()
             prefix, blocks = [], 0
+            # every product of the phase cut into the same number of K-chunks: blocks ordered K-chunk
+            # first (prefix counts output tiles), so products sharing an operand meet its rows in L2
+            nzs = {(e[2] + e[11] - 1) // e[11] for e in sel}
+            nz = nzs.pop() if len(nzs) == 1 else 0
             for i, (_, A, K, B, sbk, sbn, segT, a_seg, b_seg, shift, N, kchunk, soff, slab, nblk) in enumerate(sel):
                 arr[i] = S2GGemm(A, 1, G4, B, sbk, sbn, ptr(slabs, soff), N, slab, None, G4, N, K, kchunk, segT,
                                  a_seg, b_seg, int(shift), 0, 0, 1.0)
                 prefix.append(blocks)
-                blocks += nblk
+                blocks += (N + 63) // 64 if nz else nblk
             prefix.append(blocks)
+            if nz:
+                blocks *= nz
             raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(eng.device)
             pre = torch.tensor(prefix, dtype=torch.int32, device=eng.device)
-            tables[ph] = (raw, pre, len(sel), blocks)
+            tables[ph] = (raw, pre, len(sel), blocks, nz)
         cache = (sig, tables)
         eng._gemm_tables[cache_key] = cache
     return cache[1], job_slabs, slabs
@@ -428,9 +435,9 @@ def _wgrad_build(eng: "CriticEngine", jobs, cache_key):
 def _wgrad_launch(eng: "CriticEngine", built, phase: int) -> None:
     t = built[0].get(phase)
     if t is not None:
-        raw, pre, nprob, nblocks = t
+        raw, pre, nprob, nblocks, nz = t
         eng.timed(f"s2g_k_gemm_grouped#{phase}",
-                  lambda: call("s2g_gemm_grouped", ptr(raw), ptr(pre), nprob, nblocks, stream_ptr()))
+                  lambda: call("s2g_gemm_grouped", ptr(raw), ptr(pre), nprob, nblocks, nz, stream_ptr()))
 
 
 def _wgrad_reduce(eng: "CriticEngine", built, early: bool = False) -> None:
@@ -562,15 +569,18 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         (ptr(d0, oi), n3, ptr(ws["G"]), V, 1, 0, 0, 0, False, 0),
         (ptr(a0), B * T, ptr(ws["xhat"]), V, 1, T, Tw, T, False, 2)]),
             (g["lstm.weight_hh_l0"], H, [
-        (ptr(d0), n12, ptr(c0, 2), G4, 4, Tw, Tw, Tw, True, 0),
+        (ptr(d0), n3, ptr(c0, 2), G4, 4, Tw, Tw, Tw, True, 0),
+        (ptr(d0, oi // 2), n3, ptr(c0, oi // 2 + 2), G4, 4, Tw, Tw, Tw, True, 0),
         (ptr(a0), n3, ptr(c0, oi + 2), G4, 4, Tw, Tw, Tw, True, 2),
         (ptr(d0, oi), n3, ptr(cd0, 1), G4, 4, Tw, Tw, Tw, True, 1)]),
             (g["lstm.weight_ih_l1"], H, [
-        (ptr(d1), n12, ptr(c0, 3), G4, 4, 0, 0, 0, False, 0),
+        (ptr(d1), n3, ptr(c0, 3), G4, 4, 0, 0, 0, False, 0),
+        (ptr(d1, oi // 2), n3, ptr(c0, oi // 2 + 3), G4, 4, 0, 0, 0, False, 0),
         (ptr(a1), n3, ptr(c0, oi + 3), G4, 4, 0, 0, 0, False, 2),
         (ptr(d1, oi), n3, ptr(cd0, 2), G4, 4, 0, 0, 0, False, 1)]),
             (g["lstm.weight_hh_l1"], H, [
-        (ptr(d1), n12, ptr(c1, 2), G4, 4, Tw, Tw, Tw, True, 0),
+        (ptr(d1), n3, ptr(c1, 2), G4, 4, Tw, Tw, Tw, True, 0),
+        (ptr(d1, oi // 2), n3, ptr(c1, oi // 2 + 2), G4, 4, Tw, Tw, Tw, True, 0),
         (ptr(a1), n3, ptr(c1, oi + 2), G4, 4, Tw, Tw, Tw, True, 2),
         (ptr(d1, oi), n3, ptr(cd1, 1), G4, 4, Tw, Tw, Tw, True, 1)])]
     built = _wgrad_build(eng, jobs, ("critic", B, T, Tf, fake.data_ptr()))

@@ -53,7 +53,7 @@ SIGNATURES = {
     "s2g_argmax_rows": [P, P, L, I, P],
     "s2g_gemm_f32": [ctypes.POINTER(S2GGemm), I, P],
     "s2g_gemm_tall": [P, L, P, L, P, L, I, I, I, P],
-    "s2g_gemm_grouped": [P, P, I, I, P],
+    "s2g_gemm_grouped": [P, P, I, I, I, P],
     "s2g_critic_update": [ctypes.POINTER(S2GCriticUpdate), P],
     "s2g_reduce_slabs": [P, L, I, I, I, P, I, I, F, P],
     "s2g_reduce_slabs_multi": [P, I, I, I, F, P],

@@ -78,7 +78,7 @@ def test_gemm_grouped_matches_torch():
     prefix.append(blocks)
     raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(DEV)
     pre = torch.tensor(prefix, dtype=torch.int32, device=DEV)
-    call("s2g_gemm_grouped", ptr(raw), ptr(pre), len(probs), blocks, stream_ptr())
+    call("s2g_gemm_grouped", ptr(raw), ptr(pre), len(probs), blocks, 0, stream_ptr())
     torch.cuda.synchronize()
     for out, want in zip(outs, (want1, want2, want3)):
         assert rel(out.double().sum(0), want) < 1e-5
