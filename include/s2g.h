@@ -70,6 +70,11 @@ int s2g_gemm_f32(const S2GGemm* args, int nsplit, void* stream);
  * column roundup(N, 4).  A and B are each read once per 64-row block. */
 int s2g_gemm_tall(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N, int K,
                   void* stream);
+/* nn.Linear forward for a small batch and many output features (the generator's 512 -> L*V output layer,
+ * wgan_gp.py:159): y[batch, n_out] = x[batch, K] W[n_out, K]^T + bias; batch <= 64, n_out % 16 == 0,
+ * K % 128 == 0, K <= 512, W / y / bias 16-byte aligned.  W is streamed from HBM exactly once. */
+int s2g_linear_small_batch(const float* W, const float* x, const float* bias, float* y, int n_out, int batch, int K,
+                           void* stream);
 /* nprob problems in ONE launch.  table_dev / prefix_dev are DEVICE arrays: S2GGemm[nprob] (every
  * problem of the weight-gradient shape: A = [rows, M] with sam == 1, M % 4 == 0, M <= 208,
  * sak % 4 == 0 and a 16-byte aligned base, kchunk > 0 set by the caller, no bias / act /

@@ -815,6 +815,138 @@ extern "C" int s2g_launch_gemm_tall(const float* A, long lda, const float* B, lo
   return -1;
 }
 
+// y[M, N] = x[M, K] W[N, K]^T + bias for a small batch M <= 64 and a large N (the generator's 512 -> L*V
+// output layer: 183 MB of weights against 23 MB of outputs): bound by streaming W once from HBM, so W never
+// passes through LDS.  x^T sits in LDS (Xs[k][m], the MFMA B operand, once per workgroup); a wave owns 16
+// output features at a time and loads their W rows straight into the A-operand layout of
+// v_mfma_f32_16x16x4_f32: lane (i = l % 16, kk = l / 16) fetches the 32 bytes W[n0 + i][32 g + 8 kk .. + 7]
+// (the four lanes of a row cover one full 128-byte line), and MFMA call c of group g multiplies component
+// c of every lane's eight floats, i.e. k = 32 g + 8 kk + c, with
+// Xs rows of the same k (the reduction index may be visited in any order).  Four groups (8 KB per wave,
+// 88 KB per CU) are in flight ahead of the MFMAs.  Workgroups of 11 waves, one per CU, stride over the
+// N / 16 feature tiles (89600 / 16 = 5600 = 1.99 tiles per wave on 256 CUs).
+#define WS_LD 66          // Xs row: 8 * 66 = 16 mod 64 floats between the k rows one fragment read touches
+#define WS_WAVES 11
+#define WS_PF 4           // ring depth in groups of 32 k (two float4 per lane each)
+extern "C" __global__ __launch_bounds__(64 * WS_WAVES) void s2g_k_linear_wstream(
+    const float* __restrict__ W, const float* __restrict__ X, const float* __restrict__ bias, float* __restrict__ Y,
+    int N, int M, int K) {
+  extern __shared__ __attribute__((aligned(16))) float Xs[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // x^T into LDS: four independent 16-byte loads in flight per thread (one at a time, this loop alone cost
+  // tens of microseconds of exposed latency)
+  const int k4n = K >> 2, total4 = 64 * k4n;
+  for (int base = tid; base < total4; base += 4 * 64 * WS_WAVES) {
+    float4 v[4];
+    int mm[4], kq[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = base + u * 64 * WS_WAVES;
+      mm[u] = idx / k4n;
+      kq[u] = 4 * (idx - mm[u] * k4n);
+      v[u] = gload4(X + ((idx < total4 && mm[u] < M) ? (long)mm[u] * K + kq[u] : 0));
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = base + u * 64 * WS_WAVES;
+      if (idx < total4) {
+        const bool live = mm[u] < M;
+        float* d = Xs + kq[u] * WS_LD + mm[u];
+        d[0] = live ? v[u].x : 0.0f; d[WS_LD] = live ? v[u].y : 0.0f;
+        d[2 * WS_LD] = live ? v[u].z : 0.0f; d[3 * WS_LD] = live ? v[u].w : 0.0f;
+      }
+    }
+  }
+  __syncthreads();
+  const int ntile = N >> 4, ngrp = K >> 5;
+  const int i = lane & 15, kk = lane >> 4;
+  const int boff = 8 * kk * WS_LD + i;
+  for (int tile = blockIdx.x * WS_WAVES + wave; tile < ntile; tile += gridDim.x * WS_WAVES) {
+    const int n0 = tile << 4;
+    const float* wp = W + (long)(n0 + i) * K + 8 * kk;
+    float4 ring[WS_PF][2];
+#pragma unroll
+    for (int e = 0; e < WS_PF; ++e) {
+      ring[e][0] = gload4(wp + 32 * e);
+      ring[e][1] = gload4(wp + 32 * e + 4);
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    // Straight-line body (K % 128 == 0, all four batch tiles: rows m >= M of Xs are zero): a branch around
+    // a load or an LDS read makes the compiler drain the counters at the join.  The scheduling barriers
+    // keep each refill of the ring and the LDS reads of the NEXT half group in front of this one's MFMAs
+    // (left alone the compiler sinks all refills behind the MFMAs and then waits for them at once).
+    float bq[2][16];
+    auto bfrag = [&](int g, int h, float (&b)[16]) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[4 * c + j] = Xs[boff + (32 * g + 4 * h + c) * WS_LD + 16 * j];
+    };
+    bfrag(0, 0, bq[0]);
+    for (int g0 = 0; g0 < ngrp; g0 += WS_PF) {
+#pragma unroll
+      for (int e = 0; e < WS_PF; ++e) {
+        const int g = g0 + e;
+        const float4 w0 = ring[e][0], w1 = ring[e][1];
+        const int gn = g + WS_PF < ngrp ? g + WS_PF : 0;         // unconditional, clamped refill
+        ring[e][0] = gload4(wp + 32 * gn);
+        ring[e][1] = gload4(wp + 32 * gn + 4);
+        bfrag(g, 1, bq[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        const float wa[4] = {w0.x, w0.y, w0.z, w0.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c], bq[0][4 * c + j], acc[j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        bfrag(g + 1 < ngrp ? g + 1 : 0, 0, bq[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        const float wb[4] = {w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[c], bq[1][4 * c + j], acc[j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // D[4 kk + r][i]: feature n0 + 4 kk + r, batch row 16 j + i
+    const int n = n0 + 4 * kk;
+    const float4 bv = bias ? gload4(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = 16 * j + i;
+      if (m < M)
+        *reinterpret_cast<float4*>(Y + (long)m * N + n) =
+            make_float4(acc[j][0] + bv.x, acc[j][1] + bv.y, acc[j][2] + bv.z, acc[j][3] + bv.w);
+    }
+  }
+}
+
+extern "C" int s2g_launch_linear_wstream(const float* W, const float* X, const float* bias, float* Y, int N, int M,
+                                         int K, hipStream_t stream) {
+  const size_t lds = (size_t)K * WS_LD * sizeof(float);
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -2;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&s2g_k_linear_wstream),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2;
+    cus = prop.multiProcessorCount;
+  }
+  int blocks = ((N >> 4) + WS_WAVES - 1) / WS_WAVES;
+  if (blocks > cus) blocks = cus;
+  hipLaunchKernelGGL(s2g_k_linear_wstream, dim3(blocks), dim3(64 * WS_WAVES), lds, stream, W, X, bias, Y, N, M, K);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 extern "C" int s2g_launch_gemm(const GemmArgs* ga, int nsplit, hipStream_t stream) {
   GemmArgs g = *ga;
   if (g.M <= 0 || g.N <= 0 || g.K < 0 || nsplit < 1) return -1;

@@ -55,6 +55,14 @@ int s2g_gemm_tall(const float* A, long lda, const float* B, long ldb, float* C, 
   return s2g_launch_gemm_tall(A, lda, B, ldb, C, ldc, M, N, K, ST(stream));
 }
 
+int s2g_linear_small_batch(const float* W, const float* x, const float* bias, float* y, int n_out, int batch, int K,
+                           void* stream) {
+  if (!W || !x || !y || n_out <= 0 || batch <= 0 || batch > 64 || K <= 0) return -1;
+  if ((n_out & 15) || (K & 127) || K > 512) return -1;                      // x^T must fit in LDS: K * 272 bytes
+  if ((((uintptr_t)W) | ((uintptr_t)y) | ((uintptr_t)bias)) & 15) return -1;
+  return s2g_launch_linear_wstream(W, x, bias, y, n_out, batch, K, ST(stream));
+}
+
 int s2g_gemm_grouped(const GemmArgs* table_dev, const int* prefix_dev, int nprob, int total_blocks, int nz,
                      void* stream) {
   if (!table_dev || !prefix_dev || nprob <= 0 || nprob > 64 || total_blocks <= 0 || nz < 0) return -1;

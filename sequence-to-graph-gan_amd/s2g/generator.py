@@ -117,7 +117,7 @@ class GeneratorEngine:
         if self.last_layer_ready is not None:
             # the output Linear's update may still be running on another stream (trainer._generator_step)
             torch.cuda.current_stream().wait_event(self.last_layer_ready)
-        ops.linear_fwd(a3, p["model.8.weight"], p["model.8.bias"], logits)
+        ops.linear_fwd_small_batch(a3, p["model.8.weight"], p["model.8.bias"], logits)
         y, y_soft = ops.gumbel_softmax_fwd(logits.view(B, self.L, self.V), U if mode == 0 else None, tau, mode,
                                            hard, out=out)
         if save:
