@@ -823,10 +823,11 @@ extern "C" int s2g_launch_gemm_tall(const float* A, long lda, const float* B, lo
 // (the four lanes of a row cover one full 128-byte line), and MFMA call c of group g multiplies component
 // c of every lane's eight floats, i.e. k = 32 g + 8 kk + c, with
 // Xs rows of the same k (the reduction index may be visited in any order).  Four groups (8 KB per wave,
-// 88 KB per CU) are in flight ahead of the MFMAs.  Workgroups of 11 waves, one per CU, stride over the
-// N / 16 feature tiles (89600 / 16 = 5600 = 1.99 tiles per wave on 256 CUs).
+// 64 KB per CU) are in flight ahead of the MFMAs.  Workgroups of 8 waves, one per CU (x^T takes 135 KB of
+// LDS), stride over the N / 16 feature tiles.  Measured 70-77 us at N = 89600 (generic 64x64 tiles: 80 us;
+// with 1/16 of the MFMAs 45 us, without the in-loop loads 71 us: the MFMA + LDS-read loop is what is left).
 #define WS_LD 66          // Xs row: 8 * 66 = 16 mod 64 floats between the k rows one fragment read touches
-#define WS_WAVES 11
+#define WS_WAVES 8
 #define WS_PF 4           // ring depth in groups of 32 k (two float4 per lane each)
 extern "C" __global__ __launch_bounds__(64 * WS_WAVES) void s2g_k_linear_wstream(
     const float* __restrict__ W, const float* __restrict__ X, const float* __restrict__ bias, float* __restrict__ Y,

@@ -101,6 +101,16 @@ int main() {
       printf("32x32x2  blocks=%d threads=%d: %.3f ms  %.1f TFLOP/s\n", blocks, threads, ms, fl / ms * 1e-9);
     }
   }
+  {
+    float ms = timeit([&] { hipLaunchKernelGGL(k16<4>, dim3(256), dim3(512), 0, 0, out, iters, 1.0f, 2.0f); });
+    printf("16x16x4  4 accumulators (dependent every 4th MFMA) blocks=256 threads=512: %.1f TFLOP/s\n",
+           256.0 * 8 * iters * 4 * 2048.0 / ms * 1e-9);
+    ms = timeit([&] { hipLaunchKernelGGL(k16<2>, dim3(256), dim3(512), 0, 0, out, iters, 1.0f, 2.0f); });
+    printf("16x16x4  2 accumulators (dependent every 2nd MFMA) blocks=256 threads=512: %.1f TFLOP/s\n",
+           256.0 * 8 * iters * 2 * 2048.0 / ms * 1e-9);
+    ms = timeit([&] { hipLaunchKernelGGL(k16<4>, dim3(256), dim3(256), 0, 0, out, iters, 1.0f, 2.0f); });
+    printf("16x16x4  4 accumulators, one wave per SIMD: %.1f TFLOP/s\n", 256.0 * 4 * iters * 4 * 2048.0 / ms * 1e-9);
+  }
   for (int blocks : {256, 512}) {
     float ms = timeit([&] { hipLaunchKernelGGL(k16_lds, dim3(blocks), dim3(512), 0, 0, out, iters); });
     double fl = (double)blocks * 8 * iters * 13 * 2048.0;
