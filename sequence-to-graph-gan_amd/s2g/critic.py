@@ -656,11 +656,13 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
                 prefetch()          # not part of the join: it may run on beside this iteration's tail
         if prefetch is not None and eng.stream_g is not None:
             # The hook's work (not part of the join) goes to the masked stream of its own.  Its light part
-            # starts right away; its heavy, HBM-bound part (the generator's output layer) waits for the
-            # phase-0 and phase-1 products: run side by side the two slow each other down by more than
-            # running them one after the other costs (341 + 289 us against 200 + 83 us).
+            # starts right away; its heavy, HBM-bound part (the generator's output layer, 183 MB of weights)
+            # waits for sweep C: beside the phase-0 products it slows them past the end of sweep C (308
+            # against 217 us), while started with sweep D it is through before the last products begin,
+            # which then run alone (65 against 113 us when it only started after the phase-1 products;
+            # those take 109 instead of 50 us beside it, hidden under sweep D's 270).
             with torch.cuda.stream(eng.stream_g):
-                prefetch(lambda: eng.stream_g.wait_event(join))
+                prefetch(lambda: eng.stream_g.wait_event(after_c))
         if idle is not None and own:
             with torch.cuda.stream(stream_c):      # free while the sweeps run on the caller's stream
                 stream_c.wait_event(fork)
