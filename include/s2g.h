@@ -72,9 +72,11 @@ int s2g_gemm_tall(const float* A, long lda, const float* B, long ldb, float* C, 
                   void* stream);
 /* nn.Linear forward for a small batch and many output features (the generator's 512 -> L*V output layer,
  * wgan_gp.py:159): y[batch, n_out] = x[batch, K] W[n_out, K]^T + bias; batch <= 64, n_out % 16 == 0,
- * K % 128 == 0, K <= 512, W / y / bias 16-byte aligned.  W is streamed from HBM exactly once. */
+ * K % 128 == 0, K <= 512, W / y / bias 16-byte aligned.  W is streamed from HBM exactly once.
+ * max_workgroups: the number of CUs `stream` can reach when it is CU-masked (a workgroup takes a whole
+ * CU; more workgroups than that would run in two rounds), 0 = all CUs of the device. */
 int s2g_linear_small_batch(const float* W, const float* x, const float* bias, float* y, int n_out, int batch, int K,
-                           void* stream);
+                           int max_workgroups, void* stream);
 /* nprob problems in ONE launch.  table_dev / prefix_dev are DEVICE arrays: S2GGemm[nprob] (every
  * problem of the weight-gradient shape: A = [rows, M] with sam == 1, M % 4 == 0, M <= 208,
  * sak % 4 == 0 and a 16-byte aligned base, kchunk > 0 set by the caller, no bias / act /

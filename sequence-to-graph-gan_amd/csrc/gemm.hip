@@ -930,8 +930,10 @@ extern "C" __global__ __launch_bounds__(64 * WS_WAVES) void s2g_k_linear_wstream
   }
 }
 
+// max_workgroups: CUs the stream can reach (a CU-masked stream: fewer than the device has; a workgroup takes
+// a whole CU, so a grid larger than that would run in two rounds); 0 = all of the device's.
 extern "C" int s2g_launch_linear_wstream(const float* W, const float* X, const float* bias, float* Y, int N, int M,
-                                         int K, hipStream_t stream) {
+                                         int K, int max_workgroups, hipStream_t stream) {
   const size_t lds = (size_t)K * WS_LD * sizeof(float);
   static int cus = 0;
   if (!cus) {
@@ -943,7 +945,8 @@ extern "C" int s2g_launch_linear_wstream(const float* W, const float* X, const f
     cus = prop.multiProcessorCount;
   }
   int blocks = ((N >> 4) + WS_WAVES - 1) / WS_WAVES;
-  if (blocks > cus) blocks = cus;
+  const int cap = (max_workgroups > 0 && max_workgroups < cus) ? max_workgroups : cus;
+  if (blocks > cap) blocks = cap;
   hipLaunchKernelGGL(s2g_k_linear_wstream, dim3(blocks), dim3(64 * WS_WAVES), lds, stream, W, X, bias, Y, N, M, K);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

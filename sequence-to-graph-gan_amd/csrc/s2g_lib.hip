@@ -56,11 +56,12 @@ int s2g_gemm_tall(const float* A, long lda, const float* B, long ldb, float* C, 
 }
 
 int s2g_linear_small_batch(const float* W, const float* x, const float* bias, float* y, int n_out, int batch, int K,
-                           void* stream) {
+                           int max_workgroups, void* stream) {
   if (!W || !x || !y || n_out <= 0 || batch <= 0 || batch > 64 || K <= 0) return -1;
   if ((n_out & 15) || (K & 127) || K > 512) return -1;                      // x^T must fit in LDS: K * 272 bytes
   if ((((uintptr_t)W) | ((uintptr_t)y) | ((uintptr_t)bias)) & 15) return -1;
-  return s2g_launch_linear_wstream(W, x, bias, y, n_out, batch, K, ST(stream));
+  if (max_workgroups < 0) return -1;
+  return s2g_launch_linear_wstream(W, x, bias, y, n_out, batch, K, max_workgroups, ST(stream));
 }
 
 int s2g_gemm_grouped(const GemmArgs* table_dev, const int* prefix_dev, int nprob, int total_blocks, int nz,

@@ -70,6 +70,7 @@ class CriticEngine:
         self._gemm_tables = {}        # cached device-side problem tables of the grouped weight-gradient GEMM
         self._wgrad_slabs = None      # split-K slabs of the weight-gradient products
         self._pending_built = None    # weight-gradient plan whose final reduce was left to fused_update
+        self.cu_masked = 0            # CUs the masked side streams can reach (0 until side() has made them)
         self.overlap = True           # run the work that does not depend on sweeps C/D beside them (critic_iteration)
         self._side = None             # (stream, fork event, join event, scratch) of that second stream
         self.stream_g = None          # CU-masked stream of the prefetch hook (created with _side)
@@ -217,6 +218,7 @@ class CriticEngine:
             mask = (ctypes.c_uint32 * words)()
             for i in range(n_cu * 3 // 4):
                 mask[i // 32] |= 1 << (i % 32)
+            self.cu_masked = n_cu * 3 // 4
             handle = ctypes.c_void_p()
             try:
                 call("s2g_stream_create_cu_mask", mask, words, ctypes.byref(handle))

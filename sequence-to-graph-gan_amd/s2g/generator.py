@@ -84,10 +84,11 @@ class GeneratorEngine:
 
     def forward(self, z: torch.Tensor, labels: torch.Tensor, U: Optional[torch.Tensor], tau: float, hard: bool,
                 training: bool = True, save: bool = True, act: str = "gumbel_softmax",
-                out: Optional[torch.Tensor] = None, heavy_after=None) -> torch.Tensor:
+                out: Optional[torch.Tensor] = None, heavy_after=None, workgroups: int = 0) -> torch.Tensor:
         """heavy_after: optional callable run between the small layers and the output Linear; a caller
         that runs this forward beside other work makes the current stream wait for an event in it, so
-        that the HBM-bound part (183 MB of weights) does not collide with its own heavy kernels."""
+        that the HBM-bound part (183 MB of weights) does not collide with its own heavy kernels.
+        workgroups: CUs the current stream can reach when it is CU-masked (sizes the output layer's grid)."""
         ops._chk(z, name="noise")
         ops._chk(labels, torch.int64, "labels")
         B = z.shape[0]
@@ -117,7 +118,7 @@ class GeneratorEngine:
         if self.last_layer_ready is not None:
             # the output Linear's update may still be running on another stream (trainer._generator_step)
             torch.cuda.current_stream().wait_event(self.last_layer_ready)
-        ops.linear_fwd_small_batch(a3, p["model.8.weight"], p["model.8.bias"], logits)
+        ops.linear_fwd_small_batch(a3, p["model.8.weight"], p["model.8.bias"], logits, workgroups)
         y, y_soft = ops.gumbel_softmax_fwd(logits.view(B, self.L, self.V), U if mode == 0 else None, tau, mode,
                                            hard, out=out)
         if save:

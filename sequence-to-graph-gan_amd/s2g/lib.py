@@ -54,7 +54,7 @@ SIGNATURES = {
     "s2g_gemm_f32": [ctypes.POINTER(S2GGemm), I, P],
     "s2g_gemm_tall": [P, L, P, L, P, L, I, I, I, P],
     "s2g_gemm_grouped": [P, P, I, I, I, P],
-    "s2g_linear_small_batch": [P, P, P, P, I, I, I, P],
+    "s2g_linear_small_batch": [P, P, P, P, I, I, I, I, P],
     "s2g_critic_update": [ctypes.POINTER(S2GCriticUpdate), P],
     "s2g_reduce_slabs": [P, L, I, I, I, P, I, I, F, P],
     "s2g_reduce_slabs_multi": [P, I, I, I, F, P],

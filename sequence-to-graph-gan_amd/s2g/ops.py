@@ -94,9 +94,11 @@ def linear_fwd(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], y: t
     gemm_raw(ptr(x), K, 1, ptr(W), 1, K, ptr(y), N, M, N, K, bias=ptr(b), act=act)
 
 
-def linear_fwd_small_batch(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], y: torch.Tensor) -> None:
+def linear_fwd_small_batch(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], y: torch.Tensor,
+                           workgroups: int = 0) -> None:
     """y[M,N] = x[M,K] @ W[N,K]^T + b for a batch M <= 64 and a large N (the generator's output layer): the
-    weight is streamed from HBM exactly once; other shapes go to linear_fwd."""
+    weight is streamed from HBM exactly once; other shapes go to linear_fwd.  workgroups: CUs the current
+    stream can reach if it is CU-masked (0: the whole device)."""
     M, K = x.shape
     N = W.shape[0]
     if M > 64 or N < 4096 or N % 16 or K % 128 or K > 512:
@@ -105,7 +107,7 @@ def linear_fwd_small_batch(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.T
     _chk(x, name="x"); _chk(W, name="W"); _chk(y, name="y")
     if W.shape[1] != K or tuple(y.shape) != (M, N):
         raise S2GError("linear_fwd_small_batch: shape mismatch")
-    call("s2g_linear_small_batch", ptr(W), ptr(x), ptr(b), ptr(y), N, M, K, stream_ptr())
+    call("s2g_linear_small_batch", ptr(W), ptr(x), ptr(b), ptr(y), N, M, K, int(workgroups), stream_ptr())
 
 
 def linear_bwd_dx(dy: torch.Tensor, W: torch.Tensor, dx: torch.Tensor, scratch: Scratch) -> None:

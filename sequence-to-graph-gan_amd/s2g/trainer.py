@@ -160,7 +160,7 @@ class WGANGPTrainer:
                 if nxt["z"] is None:        # drawn on the prefetch stream: nothing of it sits on the caller's
                     nxt["z"] = torch.randn(B, LATENT, device=dev)
                 self.G.forward(nxt["z"], nxt["labels"], next_batch.get("U"), self.tau, self.hard, training=True,
-                               save=False, out=other, heavy_after=heavy_after)
+                               save=False, out=other, heavy_after=heavy_after, workgroups=self.D.cu_masked)
                 nxt["done"].record()
 
             def idle():
@@ -184,7 +184,7 @@ class WGANGPTrainer:
 
             def prefetch(heavy_after=None):
                 gp["fake"] = self.G.forward(z, labels, gp["U"], self.tau, self.hard, training=True, save=True,
-                                            heavy_after=heavy_after)
+                                            heavy_after=heavy_after, workgroups=self.D.cu_masked)
                 gp["done"].record()
 
             def idle():
