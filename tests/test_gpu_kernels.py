@@ -83,6 +83,30 @@ def test_gemm_grouped_matches_torch():
     for out, want in zip(outs, (want1, want2, want3)):
         assert rel(out.double().sum(0), want) < 1e-5
 
+    # K-chunk-first block order: every problem cut into the same number of chunks, prefix counts tiles
+    K = nb * Tw
+    probs = [(A2, K, ptr(cell, 2), 200, 4, Tw, Tw, Tw, 1, 50), (A2, K, ptr(B1), 175, 1, 0, 0, 0, 0, 175),
+             (A3, K, ptr(cell, 1), 200, 4, 0, 0, 0, 0, 50)]
+    kchunk = 64
+    nz = (K + kchunk - 1) // kchunk
+    arr = (S2GGemm * len(probs))()
+    outs, prefix, tiles = [], [], 0
+    for i, (A, K_, Bp, sbk, sbn, segT, a_seg, b_seg, shift, N) in enumerate(probs):
+        out = torch.full((nz, 200, N), float("nan"), device=DEV)
+        outs.append(out)
+        arr[i] = S2GGemm(ptr(A), 1, 200, Bp, sbk, sbn, ptr(out), N, 200 * N, None, 200, N, K_, kchunk, segT, a_seg,
+                         b_seg, shift, 0, 0, 1.0)
+        prefix.append(tiles)
+        tiles += (N + 63) // 64
+    prefix.append(tiles)
+    raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(DEV)
+    pre = torch.tensor(prefix, dtype=torch.int32, device=DEV)
+    call("s2g_gemm_grouped", ptr(raw), ptr(pre), len(probs), tiles * nz, nz, stream_ptr())
+    torch.cuda.synchronize()
+    wants = (want2, A2.double().T @ B1.double()[:K], A3.double().T @ cell[:, :, 1].double())
+    for out, want in zip(outs, wants):
+        assert rel(out.double().sum(0), want) < 1e-5
+
 
 def test_dropout_mask_matches_torch():
     from s2g.lib import call
