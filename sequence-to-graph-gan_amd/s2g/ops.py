@@ -144,6 +144,10 @@ def colsum(X: torch.Tensor, rows: int, cols: int, ld: int, out: torch.Tensor, sc
     """out[c] (+)= sum_r X[row0 + r][c]"""
     rpc = max(64, (rows + 255) // 256)
     nch = (rows + rpc - 1) // rpc
+    if nch == 1 and not permute_rows and not accumulate:
+        # a single chunk of rows: its "partial" sums are the result (saves the reduce launch)
+        call("s2g_colsum", ptr(X, row0 * ld), ld, rows, cols, ptr(out), rpc, stream_ptr())
+        return
     part = scratch.get(nch * cols)
     call("s2g_colsum", ptr(X, row0 * ld), ld, rows, cols, ptr(part), rpc, stream_ptr())
     if permute_rows:
