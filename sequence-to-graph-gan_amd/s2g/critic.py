@@ -556,9 +556,10 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
     ops.gemm_tall(ptr(ws["delta0"], r_int * G4), G4, ptr(eng.m2()), G4, ptr(ws["Pv"]), G4, B * Tw, G4, G4)
     # only the reduction stays on the critical path: sweep C scales its own seed by coef_b, and the
     # penalty values / norms come out beside it (first_order)
-    call("s2g_gp_dots", ptr(ws["delta0"], r_int * G4), ptr(ws["Pv"]), B, Tw * G4, ptr(ws["gp_partial"]), st)
+    def gp_dots():
+        call("s2g_gp_dots", ptr(ws["delta0"], r_int * G4), ptr(ws["Pv"]), B, Tw * G4, ptr(ws["gp_partial"]),
+             stream_ptr())
     gp = (ws["gp_partial"], float(lambda_gp), float(n_global))
-    lam = eng.device_scalar(float(lambda_gp))
     d0, d1, c0, c1 = ws["delta0"], ws["delta1"], ws["cell0"], ws["cell1"]
     a0, a1, cd0, cd1 = ws["abar0"], ws["abar1"], ws["celld0"], ws["celld1"]
     oi = r_int * G4
@@ -592,10 +593,12 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         """Everything that needs sweeps A and B only: operands of the products, their phase-0 part, the
         first-order bias gradients."""
         s_ = stream_ptr()
-        call("s2g_gp_penalty_final", ptr(ws["gp_partial"]), B, ptr(ws["pen"]), ptr(ws["norms"]), s_)
-        # v = coef_b * (delta0 W_ih0): the direction of the penalty's second-order term in input space
+        # g = delta0 W_ih0, the 175-wide input gradient itself: penalty values and norms (wgan_gp.py:255-256)
+        # and, scaled in place, v = coef_b * g: the direction of the penalty's second-order term in input
+        # space.  Nothing here waits for the reduction the caller's stream does for sweep C.
         ops.gemm_tall(ptr(ws["delta0"], r_int * G4), G4, ptr(eng.W0p), eng.Vp, ptr(ws["G"]), V, B * Tw, V, G4)
-        call("s2g_gp_scale", ptr(ws["G"]), ptr(ws["norms"]), ptr(lam), float(n_global), Tw * V, ptr(ws["G"]), B, s_)
+        call("s2g_gp_norm_penalty", ptr(ws["G"]), B, Tw * V, float(lambda_gp), float(n_global), ptr(ws["pen"]),
+             ptr(ws["norms"]), 1, s_)
         call("s2g_one_hot", ptr(tokens), ptr(lengths), T, ptr(ws["xreal"]), B * T, V, s_)
         call("s2g_gp_interp", ptr(tokens), ptr(lengths), ptr(fake), ptr(alpha), B, T, Tf, V, ptr(ws["xhat"]), s_)
         _wgrad_launch(eng, built, 0)
@@ -631,7 +634,13 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         # masked streams are blocking streams and would serialise with every launch there.
         own = cur.cuda_stream != 0
         sweeps = cur if own else stream_c
-        fork.record()
+        if own:
+            # fork BEFORE the penalty reduction: no event record sits between it and sweep C on this stream
+            fork.record()
+            gp_dots()
+        else:
+            gp_dots()
+            fork.record()
         with torch.cuda.stream(stream2):
             stream2.wait_event(fork)
             first_order(sc2)
@@ -688,6 +697,7 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
             _wgrad_reduce(eng, built)
         cur.wait_event(join_c)
     else:
+        gp_dots()
         eng.timed("s2g_k_lstm2_tangent", lambda: eng.sweep_tangent(ws, drel, B, mrel, r_int, gp))
         eng.timed("s2g_k_lstm2_bwd2", lambda: eng.sweep_bwd2(ws, drel, B, Tw, mrel, r_int, bsum=ws["bsumD"]))
         head_losses()
