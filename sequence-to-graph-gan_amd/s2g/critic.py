@@ -70,6 +70,7 @@ class CriticEngine:
         self._gemm_tables = {}        # cached device-side problem tables of the grouped weight-gradient GEMM
         self._wgrad_slabs = None      # split-K slabs of the weight-gradient products
         self._pending_built = None    # weight-gradient plan whose final reduce was left to fused_update
+        self._m2_due = False          # M2 must be rebuilt from the packed weights before its next reader
         self.cu_masked = 0            # CUs the masked side streams can reach (0 until side() has made them)
         self.overlap = True           # run the work that does not depend on sweeps C/D beside them (critic_iteration)
         self._side = None             # (stream, fork event, join event, scratch) of that second stream
@@ -127,20 +128,32 @@ class CriticEngine:
         # iteration, so with the side streams up it is built there, off the caller's stream.
         side = self._side if self.overlap else None
         if side:
-            if self._m2_events is None:
-                self._m2_events = (torch.cuda.Event(), torch.cuda.Event())
-            packed, ready = self._m2_events
-            packed.record()
-            with torch.cuda.stream(side[1]):
-                side[1].wait_event(packed)
-                ops.gemm_raw(ptr(self.W0p), self.Vp, 1, ptr(self.WT0), G4, 1, ptr(self.M2), G4, G4, G4, self.V)
-                ready.record()
-            self._m2_pending = True
+            # Not right here, beside the next fake projection (256 workgroups that want a CU each):
+            # kick_m2() starts it once that projection is on its way, beside sweep A.
+            self._m2_due = True
         else:
             ops.gemm_raw(ptr(self.W0p), self.Vp, 1, ptr(self.WT0), G4, 1, ptr(self.M2), G4, G4, G4, self.V)
 
+    def kick_m2(self) -> None:
+        """Starts a due rebuild of M2 on the fourth stream, ordered behind everything enqueued on the
+        current stream so far (the packed weights it reads are among that)."""
+        if not self._m2_due:
+            return
+        self._m2_due = False
+        side = self._side
+        if self._m2_events is None:
+            self._m2_events = (torch.cuda.Event(), torch.cuda.Event())
+        packed, ready = self._m2_events
+        packed.record()
+        with torch.cuda.stream(side[1]):
+            side[1].wait_event(packed)
+            ops.gemm_raw(ptr(self.W0p), self.Vp, 1, ptr(self.WT0), G4, 1, ptr(self.M2), G4, G4, G4, self.V)
+            ready.record()
+        self._m2_pending = True
+
     def m2(self) -> torch.Tensor:
         """M2 for a reader on the current stream (ordered behind a build that runs on the side stream)."""
+        self.kick_m2()
         if self._m2_pending:
             torch.cuda.current_stream().wait_event(self._m2_events[1])
             self._m2_pending = False
@@ -523,6 +536,7 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         ws["xhat"] = torch.empty(B * T, V, device=eng.device)
     # sweep A on 3B sequences
     eng.project(fake, ws["Pf"])
+    eng.kick_m2()          # a rebuild of M2 left over from the last update: beside sweep A, whose 192 workgroups leave CUs free
     eng.timed("s2g_k_lstm2_fwd", lambda: eng.sweep_fwd(ws, dptr, 3 * B, Tw, tokens, ws["Pf"], mask))
     inv_n = 1.0 / float(n_global)
 
