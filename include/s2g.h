@@ -128,7 +128,9 @@ int s2g_bias_sums(const float* X0, const float* X1, long rows, float* part, cons
  * Buffers indexed by workspace row: gates*, delta*, adot*, abar*, cell*, celld* are [rows, 200];
  * adj* is [rows, 100]; mask is [rows, 52] (dropout multiplier of layer-0 outputs, NULL = none);
  * hT/dhT/hdotT are [nseq, 50].  whh0/wih1/whh1 are the torch parameters [200, 50]. */
-int s2g_lstm2_fwd(const S2GSeq* seqs, int nseq, int max_len, const int* tokens, const float* WT0,
+/* tokens (optional) must lie in [0, vocab), the rows of WT0 (F.one_hot raises otherwise, wgan_gp.py:277;
+ * here an out-of-range id is clamped to the table); sequences longer than max_len are cut to max_len. */
+int s2g_lstm2_fwd(const S2GSeq* seqs, int nseq, int max_len, int vocab, const int* tokens, const float* WT0,
                   const float* P, const float* mask, const float* b0, const float* b1, const float* whh0,
                   const float* wih1, const float* whh1, float* gates0, float* cell0, float* gates1,
                   float* cell1, float* hT, void* stream);
@@ -227,7 +229,7 @@ int s2g_gp_scale(const float* g, const float* norms, const float* upstream, floa
 
 /* ---- generator glue: Generator.forward (wgan_gp.py:165-171), BatchNorm1d(n, eps=0.8) + LeakyReLU */
 int s2g_embed_mul(const float* z, const long long* labels, const float* emb, float* out, int B, int D,
-                  void* stream);
+                  int n_classes, void* stream);
 int s2g_embed_mul_bwd(const float* z, const long long* labels, const float* dout, float* demb, int B, int D,
                       int n_classes, void* stream);
 int s2g_lrelu_bwd(const float* y, float* dy, long n, void* stream);

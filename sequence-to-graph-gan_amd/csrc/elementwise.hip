@@ -8,11 +8,13 @@
 // ------------------------------------------------------------------ generator glue
 // out[b][k] = z[b][k] * emb[labels[b]][k]                                   (wgan_gp.py:166-167)
 extern "C" __global__ void s2g_k_embed_mul(const float* __restrict__ z, const long long* __restrict__ labels,
-                                           const float* __restrict__ emb, float* __restrict__ out, int B, int D) {
+                                           const float* __restrict__ emb, float* __restrict__ out, int B, int D,
+                                           int n_classes) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * D) return;
   int b = i / D, k = i % D;
-  out[i] = z[i] * emb[labels[b] * D + k];
+  const long long c = min(max(labels[b], 0LL), (long long)n_classes - 1);   // never outside the table
+  out[i] = z[i] * emb[c * D + k];
 }
 // demb[c][k] = sum_{b: labels[b]==c} z[b][k] * dout[b][k]   (16 lanes = one DPP row per (c,k), each
 // lane taking every 16th sample; blockDim.x must be a multiple of 16)
@@ -265,7 +267,7 @@ extern "C" __global__ void s2g_k_one_hot(const int* __restrict__ tokens, const i
   long r = i / V;
   int v = (int)(i % V);
   bool live = lengths ? (int)(r % T) < lengths[r / T] : true;
-  x[i] = (live && tokens[r] == v) ? 1.0f : 0.0f;
+  x[i] = (live && min(max(tokens[r], 0), V - 1) == v) ? 1.0f : 0.0f;      // ids clamped as in the forward sweep
 }
 
 // x_hat[b][t][v] = alpha_b * onehot(tok[b][t])[v] + (1 - alpha_b) * fake[b][t][v] (0 for t >= Tf)
@@ -282,7 +284,7 @@ extern "C" __global__ void s2g_k_gp_interp(const int* __restrict__ tokens, const
   if (t < lengths[b]) {
     float a = alpha[b];
     float f = (t < Tf) ? fake[((long)b * Tf + t) * V + v] : 0.0f;
-    out = (tokens[r] == v ? a : 0.0f) + (1.0f - a) * f;
+    out = (min(max(tokens[r], 0), V - 1) == v ? a : 0.0f) + (1.0f - a) * f;
   }
   xhat[i] = out;
 }
@@ -620,6 +622,7 @@ extern "C" __global__ void s2g_k_critic_batch_desc(const int* __restrict__ lengt
   if (i >= 4 * B) return;
   int kind = i / B, b = i % B;
   const int Tw = T > Tf ? T : Tf;     // workspace rows per sequence
+  const int len_b = min(max(lengths[b], 0), T);      // never beyond the rows a sequence owns
   S2GSeq s;
   // kind 3 repeats the interp sequences with rows counted from the first interp row, for the
   // second-order sweeps whose buffers hold the interp sequences only
@@ -627,12 +630,12 @@ extern "C" __global__ void s2g_k_critic_batch_desc(const int* __restrict__ lengt
   s.ws_row = r0;
   s.mask_off = use_mask ? r0 : -1;
   if (kind == 0) {
-    s.len = lengths[b]; s.tok_off = b * T; s.p_off = -1; s.p_len = 0; s.ca = 1.0f; s.cp = 0.0f;
+    s.len = len_b; s.tok_off = b * T; s.p_off = -1; s.p_len = 0; s.ca = 1.0f; s.cp = 0.0f;
   } else if (kind == 1) {
     s.len = Tf; s.tok_off = -1; s.p_off = b * Tf; s.p_len = Tf; s.ca = 0.0f; s.cp = 1.0f;
   } else {
     float a = alpha[b];
-    s.len = lengths[b]; s.tok_off = b * T; s.p_off = b * Tf; s.p_len = Tf; s.ca = a; s.cp = 1.0f - a;
+    s.len = len_b; s.tok_off = b * T; s.p_off = b * Tf; s.p_len = Tf; s.ca = a; s.cp = 1.0f - a;
   }
   seqs[i] = s;
 }

@@ -101,6 +101,7 @@ __device__ __forceinline__ float matvecT_pair(const f2 w[25], const float* slice
 
 __device__ __forceinline__ void zero_tail(float* buf, int ws_row, int len, int T, int width) {
   // rows [len, T) of this sequence <- 0 so that batched GEMMs over all rows see no stale data
+  if (len >= T) return;
   const size_t base = (size_t)(ws_row + len) * width;
   const size_t cnt = (size_t)(T - len) * width;
   for (size_t i = threadIdx.x; i < cnt; i += blockDim.x) buf[base + i] = 0.0f;
@@ -203,7 +204,8 @@ extern "C" __global__ __launch_bounds__(BWD_THREADS) void s2g_k_lstm2_bwd(
   float* dybuf = lds + 4 * DVEC;     // mask * W_ih1^T delta1 [2][64]
 
   const int n = blockIdx.x;
-  const S2GSeq sq = seqs[n];
+  S2GSeq sq = seqs[n];
+  sq.len = min(sq.len, T);      // a sequence owns T workspace rows
   const int tid = threadIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: row pointers stay scalar
   const int lane = tid & 63;
@@ -343,7 +345,8 @@ extern "C" __global__ __launch_bounds__(BWD_THREADS) void s2g_k_lstm2_bwd2(
   float* dybuf = lds + 4 * DVEC;
 
   const int n = blockIdx.x;
-  const S2GSeq sq = seqs[n];
+  S2GSeq sq = seqs[n];
+  sq.len = min(sq.len, T);      // a sequence owns T workspace rows
   const int tid = threadIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: row pointers stay scalar
   const int lane = tid & 63;

@@ -117,7 +117,7 @@ extern "C" __global__ __launch_bounds__(FWD_THREADS) void s2g_k_lstm2_fwd(
     const float* __restrict__ P, const float* __restrict__ mask, const float* __restrict__ b0,
     const float* __restrict__ b1, const float* __restrict__ whh0, const float* __restrict__ wih1,
     const float* __restrict__ whh1, float* __restrict__ gates0, float* __restrict__ cell0,
-    float* __restrict__ gates1, float* __restrict__ cell1, float* __restrict__ hT) {
+    float* __restrict__ gates1, float* __restrict__ cell1, float* __restrict__ hT, int vocab, int max_len) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* h0buf = reinterpret_cast<float*>(smem);   // [2][HV]
   float* h1buf = h0buf + 2 * HV;                    // [2][HV]
@@ -130,7 +130,7 @@ extern "C" __global__ __launch_bounds__(FWD_THREADS) void s2g_k_lstm2_fwd(
   const int tid = threadIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: role tests and row pointers stay scalar
   const int lane = tid & 63;
-  const int len = sq.len;
+  const int len = min(sq.len, max_len);      // the token stage in LDS holds max_len entries
   const bool has_tok = sq.tok_off >= 0 && sq.ca != 0.0f;
   const bool has_p = sq.p_off >= 0 && sq.cp != 0.0f && sq.p_len > 0;
   const bool has_mask = sq.mask_off >= 0 && mask != nullptr;
@@ -140,7 +140,10 @@ extern "C" __global__ __launch_bounds__(FWD_THREADS) void s2g_k_lstm2_fwd(
     return;
   }
   for (int i = tid; i < FWD_LDS_FLOATS; i += FWD_THREADS) h0buf[i] = 0.0f;
-  for (int i = tid; i < len; i += FWD_THREADS) tok_lds[i] = has_tok ? tokens[sq.tok_off + i] : 0;
+  // a token outside [0, vocab) would index past the V rows of WT0: the host wrappers reject such batches
+  // where they see them on the CPU; here the row index is clamped so that no access leaves the table
+  for (int i = tid; i < len; i += FWD_THREADS)
+    tok_lds[i] = has_tok ? min(max(tokens[sq.tok_off + i], 0), vocab - 1) : 0;
   const int nit = len + 2;                    // pipeline iterations (= barriers) of every wave
 
   if (wv >= 4) {

@@ -163,15 +163,16 @@ int s2g_bias_sums_final(const float* sums, int nseq, long layer_stride, const fl
   return LAUNCH_OK();
 }
 
-int s2g_lstm2_fwd(const S2GSeq* seqs, int nseq, int max_len, const int* tokens, const float* WT0, const float* P,
+int s2g_lstm2_fwd(const S2GSeq* seqs, int nseq, int max_len, int vocab, const int* tokens, const float* WT0, const float* P,
                   const float* mask, const float* b0, const float* b1, const float* whh0, const float* wih1,
                   const float* whh1, float* gates0, float* cell0, float* gates1, float* cell1, float* hT,
                   void* stream) {
   if (!seqs || nseq <= 0 || max_len < 0 || max_len > 16384) return -1;
+  if (tokens && (vocab <= 0 || !WT0)) return -1;
   if (!b0 || !b1 || !whh0 || !wih1 || !whh1 || !gates0 || !cell0 || !gates1 || !cell1 || !hT) return -1;
   size_t lds = FWD_LDS_FLOATS * sizeof(float) + (size_t)max_len * sizeof(int);
   hipLaunchKernelGGL(s2g_k_lstm2_fwd, dim3(nseq), dim3(FWD_THREADS), lds, ST(stream), seqs, tokens, WT0, P, mask, b0, b1,
-                     whh0, wih1, whh1, gates0, cell0, gates1, cell1, hT);
+                     whh0, wih1, whh1, gates0, cell0, gates1, cell1, hT, vocab > 0 ? vocab : 1, max_len);
   return LAUNCH_OK();
 }
 
@@ -333,10 +334,10 @@ int s2g_gp_scale(const float* g, const float* norms, const float* upstream, floa
 }
 
 int s2g_embed_mul(const float* z, const long long* labels, const float* emb, float* out, int B, int D,
-                  void* stream) {
-  if (!z || !labels || !emb || !out || B <= 0 || D <= 0) return -1;
+                  int n_classes, void* stream) {
+  if (!z || !labels || !emb || !out || B <= 0 || D <= 0 || n_classes <= 0) return -1;
   hipLaunchKernelGGL(s2g_k_embed_mul, dim3(cdiv((long)B * D, 256)), dim3(256), 0, ST(stream), z, labels, emb, out,
-                     B, D);
+                     B, D, n_classes);
   return LAUNCH_OK();
 }
 int s2g_embed_mul_bwd(const float* z, const long long* labels, const float* dout, float* demb, int B, int D,

@@ -281,7 +281,7 @@ class CriticEngine:
 
     def sweep_fwd(self, ws, desc_ptr, nseq, max_len, tokens, P, mask) -> None:
         whh0, wih1, whh1 = self._w()
-        call("s2g_lstm2_fwd", desc_ptr, nseq, max_len, ptr(tokens), ptr(self.WT0), ptr(P), ptr(mask), ptr(self.b0),
+        call("s2g_lstm2_fwd", desc_ptr, nseq, max_len, self.V, ptr(tokens), ptr(self.WT0), ptr(P), ptr(mask), ptr(self.b0),
              ptr(self.b1), whh0, wih1, whh1, ptr(ws["gates0"]), ptr(ws["cell0"]), ptr(ws["gates1"]),
              ptr(ws["cell1"]), ptr(ws["hT"]), stream_ptr())
 
@@ -346,6 +346,9 @@ def make_desc(entries, device) -> torch.Tensor:
     import numpy as np
     arr = np.zeros((len(entries), 8), dtype=np.int32)
     for i, e in enumerate(entries):
+        if e["len"] < 0 or e["ws_row"] < 0 or (e.get("p_off", -1) >= 0 and e["len"] > max(e.get("p_len", 0), 0)
+                                               and e.get("tok_off", -1) < 0):
+            raise S2GError("make_desc: a sequence needs 0 <= len (<= p_len when it has no tokens) and ws_row >= 0")
         arr[i, 0] = e["len"]; arr[i, 1] = e.get("tok_off", -1); arr[i, 2] = e.get("p_off", -1)
         arr[i, 3] = e.get("p_len", 0)
         arr[i, 4:6] = np.array([e.get("ca", 0.0), e.get("cp", 0.0)], dtype=np.float32).view(np.int32)

@@ -81,6 +81,31 @@ class CustomSequenceDataset(torch.utils.data.Dataset):
         return sample, self.labels[idx]
 
 
+def check_batch(tokens=None, labels=None, lengths=None, vocab=None, n_classes=None, T=None) -> None:
+    """Range checks of a batch while it is still on the host (no device synchronisation).  The reference
+    raises in these cases -- F.one_hot (wgan_gp.py:277), nn.Embedding (:166), pack_padded_sequence (:279) --
+    while a kernel would read or write out of bounds; each argument is optional and checked only when
+    it is a CPU tensor."""
+    from .lib import S2GError
+
+    def host(t):
+        return t is not None and isinstance(t, torch.Tensor) and not t.is_cuda and t.numel() > 0
+
+    if host(tokens) and vocab is not None:
+        lo, hi = int(tokens.min()), int(tokens.max())
+        if lo < 0 or hi >= vocab:
+            raise S2GError(f"token ids must lie in [0, {vocab}): found range [{lo}, {hi}] "
+                           "(an unknown syscall encoded as -1? add 'UNK' to the vocabulary)")
+    if host(labels) and n_classes is not None:
+        lo, hi = int(labels.min()), int(labels.max())
+        if lo < 0 or hi >= n_classes:
+            raise S2GError(f"labels must lie in [0, {n_classes}): found range [{lo}, {hi}]")
+    if host(lengths) and T is not None:
+        lo, hi = int(lengths.min()), int(lengths.max())
+        if lo < 1 or hi > T:
+            raise S2GError(f"sequence lengths must lie in [1, {T}]: found range [{lo}, {hi}]")
+
+
 def collate_fn(batch):
     """custom_dataset.py:30-47: sort by length (descending), zero-pad, return lengths."""
     batch.sort(key=lambda x: len(x[0]), reverse=True)

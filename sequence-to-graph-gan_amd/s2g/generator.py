@@ -98,7 +98,7 @@ class GeneratorEngine:
         dev = self.device
         x0 = torch.empty(B, LATENT, device=dev)
         call("s2g_embed_mul", ptr(z), ptr(labels), ptr(p["label_embedding.weight"]), ptr(x0), B, LATENT,
-             stream_ptr())
+             self.n_classes, stream_ptr())
         a1 = torch.empty(B, 128, device=dev)
         ops.linear_fwd(x0, p["model.0.weight"], p["model.0.bias"], a1, act=1)
         pre2 = torch.empty(B, 256, device=dev)

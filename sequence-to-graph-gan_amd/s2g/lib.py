@@ -61,7 +61,7 @@ SIGNATURES = {
     "s2g_colsum": [P, L, L, I, P, L, P],
     "s2g_bias_sums": [P, P, L, P, P, I, P, P, P, P, P, I, P],
     "s2g_bias_sums_final": [P, I, L, P, I, P, P, P, P, P, I, P],
-    "s2g_lstm2_fwd": [P, I, I] + [P] * 15,
+    "s2g_lstm2_fwd": [P, I, I, I] + [P] * 15,
     "s2g_lstm2_bwd": [P, I, I] + [P] * 13 + [I, I, P, P, P],
     "s2g_lstm2_tangent": [P, I] + [P] * 14 + [P, F, F, P],
     "s2g_lstm2_bwd2": [P, I, I] + [P] * 18,
@@ -81,7 +81,7 @@ SIGNATURES = {
     "s2g_gp_dots": [P, P, I, L, P, P],
     "s2g_gp_penalty_final": [P, I, P, P, P],
     "s2g_gp_scale": [P, P, P, F, L, P, I, P],
-    "s2g_embed_mul": [P, P, P, P, I, I, P],
+    "s2g_embed_mul": [P, P, P, P, I, I, I, P],
     "s2g_embed_mul_bwd": [P, P, P, P, I, I, I, P],
     "s2g_lrelu_bwd": [P, P, L, P],
     "s2g_dropout_mask": [P, L, F, P],

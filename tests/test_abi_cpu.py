@@ -52,7 +52,7 @@ def test_rejects_bad_arguments_without_a_gpu():
     l = lib.load()
     assert l.s2g_adam(None, None, None, None, 10, 1e-3, 0.5, 0.999, 1e-8, 1, 1.0, None) == -1
     assert l.s2g_gumbel_softmax_fwd(None, None, None, 0, None, None, 4, 175, 0.5, 0, 0, None) == -1
-    assert l.s2g_lstm2_fwd(None, 0, 0, *([None] * 15)) == -1
+    assert l.s2g_lstm2_fwd(None, 0, 0, 0, *([None] * 15)) == -1
     assert l.s2g_gp_norm_penalty(None, 0, 0, 1.0, 1.0, None, None, 0, None) == -1
 
 

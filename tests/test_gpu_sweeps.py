@@ -214,3 +214,31 @@ def test_token_and_interp_inputs():
     call("s2g_critic_batch_desc", ptr(len_d), ptr(alpha_d), B, T, Tf, 0, ptr(d2), stream_ptr())
     torch.cuda.synchronize()
     assert torch.equal(d2[:3 * B].cpu(), desc.cpu())
+
+
+def test_out_of_range_tokens_and_lengths_stay_in_bounds():
+    """Device tensors cannot be range-checked without a synchronisation, so the kernels themselves must not
+    leave their buffers: token ids are clamped to the rows of the W_ih0 table and lengths to the rows a
+    sequence owns.  A batch with ids -1 / 10^6 and lengths T+9 must give exactly the result of the batch
+    with those values clamped (the reference raises for such a batch, wgan_gp.py:277-279)."""
+    from s2g.trainer import WGANGPTrainer, class_weight_sum
+    DEV = "cuda:0"
+    B, T, Tf, V = 4, 16, 12, 175
+    pd, pg = common.critic_params(61, scale=2.0), common.generator_params(62, V, Tf)
+    tokens, labels, lengths = common.batch(63, B, T, lengths=[16, 16, 9, 3])
+    nz = common.noise(64, B, Tf)
+    bad_tok, bad_len = tokens.clone(), lengths.clone()
+    bad_tok[0, 3], bad_tok[1, 0], bad_tok[2, 8] = -1, 10 ** 6, 175
+    bad_len[0], bad_len[1] = T + 9, T + 1
+    ok_tok = bad_tok.clamp(0, V - 1)
+    out = []
+    for tok, ln in ((ok_tok, lengths), (bad_tok, bad_len)):
+        tr = WGANGPTrainer(V, Tf, DEV, drop_rate=0.0)
+        tr.G.load(pg); tr.D.load(pd)
+        tr.critic_step(tok.to(torch.int32).to(DEV).contiguous(), labels.to(DEV), ln.to(torch.int32).to(DEV),
+                       class_weight_sum(labels), nz["z"].to(DEV), nz["U"].to(DEV), nz["alpha"].view(-1).to(DEV))
+        torch.cuda.synchronize()
+        out.append((tr.D.params.flat.clone(), tr.last["d_parts"].clone(), tr.last["pen"].clone()))
+    for a, b in zip(*out):
+        assert torch.isfinite(b).all()
+        assert torch.equal(a, b)

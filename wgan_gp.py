@@ -116,6 +116,7 @@ class Generator(nn.Module):
     def forward(self, noise, labels, tau, hard):
         if not noise.is_cuda:
             raise S2GError("Generator.forward needs GPU tensors (MI355X-only implementation, no CPU path)")
+        s2g_data.check_batch(labels=labels, n_classes=self.n_classes)
         eng = self.engine(noise.device)
         U = None
         if self.gumbel_softmax.act == "gumbel_softmax":
@@ -163,6 +164,9 @@ class Discriminator(nn.Module):
             x, lens = packed_input, None
         if not x.is_cuda:
             raise S2GError("Discriminator.forward needs GPU tensors (MI355X-only implementation, no CPU path)")
+        if x.dim() != 3 or x.shape[2] != self.input_size:
+            raise S2GError(f"Discriminator.forward: expected [B, T, {self.input_size}] input, got {tuple(x.shape)}")
+        s2g_data.check_batch(lengths=lens, T=x.shape[1])
         eng = self.engine(x.device)
         mask = self.dropout_mask(x.shape[0], x.shape[1], x.device)
         return CriticFn.apply(eng, x, lens, mask, *[p for _, p in self.named_parameters()])
@@ -174,6 +178,10 @@ def compute_gradient_penalty(discriminator, encoded_padded_real_data, fake_data,
     alpha = rand((fake_data.size(0), 1, 1)).to(fake_data.device)
     eng = discriminator.engine(fake_data.device)
     B, T = encoded_padded_real_data.shape[0], encoded_padded_real_data.shape[1]
+    lengths = torch.as_tensor(lengths)
+    if lengths.numel() != B:
+        raise S2GError("compute_gradient_penalty: one length per sample expected")
+    s2g_data.check_batch(lengths=lengths.cpu(), T=T)
     mask = discriminator.dropout_mask(B, T, fake_data.device)
     return GradientPenaltyFn.apply(eng, encoded_padded_real_data, fake_data.detach(), alpha, torch.as_tensor(lengths),
                                    mask, *[p for _, p in discriminator.named_parameters()])
@@ -210,6 +218,8 @@ def train_wgan(generator, discriminator, optimizer_G, optimizer_D, train_dataloa
         generator.train()
         discriminator.train()
         for i, (padded_sequences, labels, lengths) in enumerate(tqdm(train_dataloader)):
+            s2g_data.check_batch(padded_sequences, labels, lengths, vocab=opt.vocab_size,
+                                 n_classes=generator.n_classes, T=padded_sequences.shape[1])
             wsum = class_weight_sum(labels)
             tok = padded_sequences.to(torch.int32).to(device).contiguous()
             lab = labels.to(device)
