@@ -171,6 +171,15 @@ int s2g_lstm2_bwd2(const S2GSeq* seqs, int nseq, int rows_per_seq, const float* 
                    const float* gates1, const float* cell1, const float* adot0, const float* celld0,
                    const float* adot1, const float* celld1, const float* adj0, const float* adj1,
                    float* abar0, float* abar1, float* bsum, void* stream);
+/* s2g_bias_sums without the `part` workspace, for callers that cannot allocate device memory (code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the
+ * reference.  The partial sums go to a file-scope device array of the library (800 KB, held by every GPU
+ * the library runs on until the process ends), so rows <= 262144; more rows return -3 and nothing is
+ * enqueued.  Calls no hipMalloc / hipFree.  All calls on one GPU share that array: two calls whose
+ * kernels may overlap (different streams without an ordering event) race; same-stream calls are safe.
+ * Results are bit-identical to s2g_bias_sums. */
+int s2g_bias_sums_noalloc(const float* X0, const float* X1, long rows, const float* hdotT, int B, float* bih0,
+                          float* bhh0, float* bih1, float* bhh1, float* fcw0, int accumulate, void* stream);
 /* bsum (optional, both reverse sweeps): [2][nseq][200]; sequence n's sums over time of its layer-0
  * (bsum[0][n]) and layer-1 (bsum[1][n]) gate gradients, i.e. its share of the bias gradients, left
  * behind by the sweep at no extra pass over memory.  s2g_bias_sums_final adds up the first nseq rows

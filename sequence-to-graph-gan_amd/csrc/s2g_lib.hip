@@ -7,6 +7,7 @@
 #include "sampler.hip"
 #include "elementwise.hip"
 #include <math.h>
+#include <mutex>
 
 #define ST(s) ((hipStream_t)(s))
 #define LAUNCH_OK() (hipGetLastError() == hipSuccess ? 0 : -2)
@@ -154,6 +155,50 @@ int s2g_bias_sums(const float* X0, const float* X1, long rows, float* part, cons
                      hdotT, B, bih0, bhh0, bih1, bhh1, fcw0, accumulate);
   return LAUNCH_OK();
 }
+// s2g_bias_sums for callers that cannot allocate (HIP graph capture, serving loops): the partial sums
+// live in a file-scope device array instead of a caller-provided workspace.  Every GPU holds its own
+// copy of the array at its own address, looked up once per device (the array's name is only a
+// host-side handle for that lookup, never a device address).
+#define S2G_NOALLOC_MAX_ROWS 262144L
+static __device__ __align__(256) float s2g_noalloc_scratch[2 * (S2G_NOALLOC_MAX_ROWS / BIAS_CHUNK) * S2G_G];
+#define S2G_MAX_DEVICES 64
+static float* s2g_noalloc_ptr[S2G_MAX_DEVICES];
+static std::mutex s2g_noalloc_lock;
+
+// device address of the scratch array on the current device (nullptr + error code on failure)
+static int s2g_noalloc_scratch_ptr(float** out) {
+  int dev = -1;
+  S2G_CHECK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= S2G_MAX_DEVICES) return -1;
+  std::lock_guard<std::mutex> guard(s2g_noalloc_lock);
+  if (!s2g_noalloc_ptr[dev]) {
+    float* p = nullptr;
+    S2G_CHECK(hipGetSymbolAddress((void**)&p, HIP_SYMBOL(s2g_noalloc_scratch)));
+    if (!p) return -2;
+    s2g_noalloc_ptr[dev] = p;
+  }
+  *out = s2g_noalloc_ptr[dev];
+  return 0;
+}
+
+int s2g_bias_sums_noalloc(const float* X0, const float* X1, long rows, const float* hdotT, int B, float* bih0,
+                          float* bhh0, float* bih1, float* bhh1, float* fcw0, int accumulate, void* stream) {
+  if (!X0 || !X1 || rows <= 0 || !bih0 || !bhh0 || !bih1 || !bhh1) return -1;
+  if (hdotT && (!fcw0 || B <= 0)) return -1;
+  if (rows > S2G_NOALLOC_MAX_ROWS) return -3;          // beyond the static scratch: use s2g_bias_sums
+  float* part = nullptr;
+  const int rc = s2g_noalloc_scratch_ptr(&part);
+  if (rc != 0) return rc;
+  // pass 1 writes every partial row pass 2 reads (nchunk rows per layer), so nothing of the array has to
+  // start at zero; what the last call left beyond them is never read
+  const int nchunk = (int)cdiv(rows, (long)BIAS_CHUNK);
+  hipLaunchKernelGGL(s2g_k_bias_sums_part, dim3(cdiv(S2G_G, 64), nchunk, 2), dim3(256), 0, ST(stream), X0, X1, rows,
+                     part);
+  hipLaunchKernelGGL(s2g_k_bias_sums_final, dim3(8), dim3(256), 0, ST(stream), part, nchunk, (long)nchunk * S2G_G,
+                     hdotT, B, bih0, bhh0, bih1, bhh1, fcw0, accumulate);
+  return LAUNCH_OK();
+}
+
 int s2g_bias_sums_final(const float* sums, int nseq, long layer_stride, const float* hdotT, int B, float* bih0,
                         float* bhh0, float* bih1, float* bhh1, float* fcw0, int accumulate, void* stream) {
   if (!sums || nseq <= 0 || layer_stride < (long)nseq * S2G_G || !bih0 || !bhh0 || !bih1 || !bhh1) return -1;

@@ -60,6 +60,7 @@ SIGNATURES = {
     "s2g_reduce_slabs_multi": [P, I, I, I, F, P],
     "s2g_colsum": [P, L, L, I, P, L, P],
     "s2g_bias_sums": [P, P, L, P, P, I, P, P, P, P, P, I, P],
+    "s2g_bias_sums_noalloc": [P, P, L, P, I, P, P, P, P, P, I, P],
     "s2g_bias_sums_final": [P, I, L, P, I, P, P, P, P, P, I, P],
     "s2g_lstm2_fwd": [P, I, I, I] + [P] * 15,
     "s2g_lstm2_bwd": [P, I, I] + [P] * 13 + [I, I, P, P, P],
