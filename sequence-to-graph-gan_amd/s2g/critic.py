@@ -75,6 +75,8 @@ class CriticEngine:
         self.overlap = True           # run the work that does not depend on sweeps C/D beside them (critic_iteration)
         self._side = None             # (stream, fork event, join event, scratch) of that second stream
         self.stream_g = None          # CU-masked stream of the prefetch hook (created with _side)
+        self.reserve_comm_stream = False   # data-parallel runs: the collective library owns a stream (and a hardware
+                                           # queue) of its own, so the prefetch hook shares the second stream instead
         self._m2_events = None        # (weights packed, M2 built) when M2 is built on a side stream
         self._m2_pending = False
         self._ws_key = None
@@ -242,8 +244,11 @@ class CriticEngine:
             handles = [handle.value]
             # a second stream under the same mask for the caller's prefetch hook, so that it runs beside
             # (not behind) this iteration's own work on the first one
+            # (not with several ranks: four hardware queues per process, and RCCL's stream takes one)
             handle_g = ctypes.c_void_p()
             try:
+                if self.reserve_comm_stream:
+                    raise S2GError("no fifth stream")
                 call("s2g_stream_create_cu_mask", mask, words, ctypes.byref(handle_g))
                 self.stream_g = torch.cuda.ExternalStream(handle_g.value, device=self.device)
                 handles.append(handle_g.value)
@@ -518,6 +523,8 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         ops._chk(t, dt, nm)
     if alpha.numel() != B or lengths.numel() != B or labels.numel() != B or fake.shape[0] != B:
         raise S2GError("critic_iteration: batch size mismatch")
+    if B > 1024:
+        raise S2GError("critic_iteration: at most 1024 sequences per GPU and batch (the loss kernels are one workgroup)")
     Tw = max(T, Tf)
     ws = eng.workspace(3 * B, Tw, B)
     eng._timed_iter += 1
@@ -546,19 +553,10 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
     def head_losses():
         """Loss values, d(out) and the fc gradients (wgan_gp.py:221, 299-313).  Sweep B derives its own
         d loss / d h_T per sequence (head_args), so this bookkeeping runs off the critical path."""
-        s_ = stream_ptr()
-        if B <= 1024:
-            # head, loss, d(out), d(hT) and the fc gradients in one single-workgroup launch
-            call("s2g_critic_head", ptr(ws["hT"]), ptr(p["fc.weight"]), ptr(p["fc.bias"]), ptr(labels), B, inv_n,
-                 inv_wsum, class_w[0], class_w[1], ptr(ws["out"]), ptr(ws["dout"]), ptr(ws["losses"]),
-                 ptr(ws["dhT"]), ptr(g["fc.weight"]), ptr(g["fc.bias"]), s_)
-        else:
-            eng.head_fwd(ws, 3 * B)
-            call("s2g_critic_loss", ptr(ws["out"]), ptr(labels), B, inv_n, inv_wsum, class_w[0], class_w[1],
-                 ptr(ws["dout"]), ptr(ws["losses"]), s_)
-            call("s2g_head_bwd_dh", ptr(ws["dout"]), ptr(p["fc.weight"]), ptr(ws["dhT"]), 3 * B, 3, s_)
-            call("s2g_head_bwd_w", ptr(ws["dout"]), ptr(ws["hT"]), ptr(g["fc.weight"]), ptr(g["fc.bias"]), 2 * B, 3,
-                 0, s_)
+        # head, loss, d(out), d(hT) and the fc gradients in one single-workgroup launch
+        call("s2g_critic_head", ptr(ws["hT"]), ptr(p["fc.weight"]), ptr(p["fc.bias"]), ptr(labels), B, inv_n,
+             inv_wsum, class_w[0], class_w[1], ptr(ws["out"]), ptr(ws["dout"]), ptr(ws["losses"]),
+             ptr(ws["dhT"]), ptr(g["fc.weight"]), ptr(g["fc.bias"]), stream_ptr())
 
     # sweep B on 3B sequences (the interp third with d(out) = e0 and stored adjoints)
     head = eng.head_args(ws, labels, B, 0, inv_n, inv_wsum, class_w)

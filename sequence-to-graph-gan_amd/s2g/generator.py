@@ -140,8 +140,8 @@ class GeneratorEngine:
         # sums are global already; the flat gradient bucket is SUM-reduced over ranks afterwards,
         # so each rank contributes 1/world of them
         share = 1.0 / float(self.comm.world)
-        torch.mul(sums[:F_], share, out=g[name + ".bias"])
-        torch.mul(sums[F_:], share, out=g[name + ".weight"])
+        ops.reduce_slabs(sums, F_, 1, 1, F_, g[name + ".bias"], scale=share)
+        ops.reduce_slabs(sums[F_:], F_, 1, 1, F_, g[name + ".weight"], scale=share)
         dpre = torch.empty_like(da)
         call("s2g_bn_bwd_apply", ptr(da), ptr(xhat), ptr(sums), float(B * self.comm.world),
              ptr(self.params.views[name + ".weight"]), ptr(inv), ptr(dpre), B, F_, stream_ptr())

@@ -28,7 +28,12 @@ class DistComm:
         self.rank = dist.get_rank(group)
 
     def allreduce(self, t: torch.Tensor) -> None:
+        """Sum over the ranks, in place, ordered behind the work enqueued on the current stream."""
         if self.world > 1:
+            if t.is_cuda and dist.get_backend(self.group) == "gloo":
+                # rehearsal on one GPU: gloo stages device tensors through the host and its own wait for a
+                # busy stream can hang with several processes on one card; drain the GPU first
+                torch.cuda.synchronize()
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     def barrier(self) -> None:

@@ -38,14 +38,19 @@ def dropout_mask(rows: int, p: float, device) -> Optional[torch.Tensor]:
 class WGANGPTrainer:
     def __init__(self, vocab: int, gen_seq_len: int, device, lr: float = 2e-4, b1: float = 0.5, b2: float = 0.999,
                  lambda_gp: float = 10.0, tau: float = 0.5, hard: bool = False, n_critic: int = 5,
-                 drop_rate: float = 0.3, comm=None, gen_engine=None, critic_engine=None):
+                 drop_rate: float = 0.3, comm=None, gen_engine=None, critic_engine=None, eps: float = 1e-8,
+                 adam_g=None):
+        """lr, b1, b2, eps: Adam hyper-parameters of the critic's optimizer (wgan_gp.py:406) and, unless
+        adam_g = (lr, b1, b2, eps) says otherwise, of the generator's (wgan_gp.py:405)."""
         self.device = torch.device(device)
         self.comm = comm or NoComm()
         self.G = gen_engine or GeneratorEngine(vocab, gen_seq_len, self.device, comm=self.comm)
         self.G.comm = self.comm
         self.D = critic_engine or CriticEngine(vocab, self.device)
+        self.D.reserve_comm_stream = self.comm.world > 1
         self.D.repack()
-        self.lr, self.b1, self.b2, self.eps = lr, b1, b2, 1e-8
+        self.lr, self.b1, self.b2, self.eps = lr, b1, b2, eps
+        self.adam_g = tuple(adam_g) if adam_g is not None else (lr, b1, b2, eps)
         self.lambda_gp, self.tau, self.hard, self.n_critic, self.drop_rate = lambda_gp, tau, hard, n_critic, drop_rate
         self.V, self.L = vocab, gen_seq_len
         self.mD_named, self.vD_named = self.D.params.like(), self.D.params.like()   # Adam moments (named views)
@@ -74,7 +79,8 @@ class WGANGPTrainer:
             return
         g = eng.grads.flat[lo:hi]
         self.comm.allreduce(g)
-        ops.adam(eng.params.flat[lo:hi], g, m[lo:hi], v[lo:hi], self.lr, self.b1, self.b2, self.eps, step)
+        lr, b1, b2, eps = self.adam_g if eng is self.G else (self.lr, self.b1, self.b2, self.eps)
+        ops.adam(eng.params.flat[lo:hi], g, m[lo:hi], v[lo:hi], lr, b1, b2, eps, step)
 
     def _fake_buf(self, which: int, B: int) -> torch.Tensor:
         # persistent output buffers: stable pointers let the grouped-GEMM problem table be reused
@@ -134,7 +140,9 @@ class WGANGPTrainer:
             torch.cuda.current_stream().wait_event(pre["done"])
             if alpha is None:
                 alpha = pre.get("alpha")
-                if pre.get("desc_key") == (B, T, self.L, pre.get("mask") is not None and mask is None):
+                # the descriptors were built with or without dropout-mask rows: reuse them only if that
+                # matches whether a mask (the caller's or the prefetched one) is used now
+                if pre.get("desc_key") == (B, T, self.L, mask is not None or pre.get("mask") is not None):
                     desc = pre["desc"]
             if mask is None and pre.get("mask") is not None and pre["mask"].shape[0] == 3 * B * max(T, self.L):
                 mask = pre["mask"]
@@ -152,7 +160,9 @@ class WGANGPTrainer:
         if mask is None and self.drop_rate > 0.0:
             mask = dropout_mask(3 * B * Tw, self.drop_rate, dev)
         prefetch = None
-        if next_batch is not None and self.D.overlap and self.comm.world == 1:
+        # (with several ranks the prefetched forwards issue their BatchNorm all-reduces from the second stream;
+        # every rank runs the same host code, so all ranks issue their collectives in the same order)
+        if next_batch is not None and self.D.overlap:
             nxt = dict(labels=next_batch["labels"], z=next_batch.get("z"), done=torch.cuda.Event())
             other = self._fake_buf(self._fake_cur ^ 1, B)
 
@@ -174,12 +184,12 @@ class WGANGPTrainer:
                     self._desc_cur ^= 1
                     if self._desc[self._desc_cur] is None or self._desc[self._desc_cur].numel() < 4 * B * 8:
                         self._desc[self._desc_cur] = torch.zeros(4 * B, 8, dtype=torch.int32, device=dev)
-                    use_mask = nxt.get("mask") is not None
+                    use_mask = next_batch.get("mask") is not None or nxt.get("mask") is not None
                     batch_desc(next_batch["lengths"], nxt["alpha"].reshape(-1), B, next_batch["T"], self.L, use_mask,
                                self._desc[self._desc_cur])
                     nxt["desc"] = self._desc[self._desc_cur]
                     nxt["desc_key"] = (B, next_batch["T"], self.L, use_mask)
-        elif gen_next is not None and self.D.overlap and self.comm.world == 1:
+        elif gen_next is not None and self.D.overlap:
             gp = dict(z=z, labels=labels, U=gen_next.get("U"), done=torch.cuda.Event())
 
             def prefetch(heavy_after=None):
@@ -296,6 +306,14 @@ class WGANGPTrainer:
         t = (l[0] + l[1]).reshape(1).clone()
         self.comm.allreduce(t)
         return t[0]
+
+    def losses(self) -> torch.Tensor:
+        """(d_loss, g_loss) of the last critic / generator step as one 2-element device tensor: the values
+        train_wgan prints (wgan_gp.py:345-348), summed over the ranks with ONE all-reduce."""
+        l, pen, gl = self.last["d_parts"], self.last["pen"], self.last["g_parts"]
+        t = torch.stack((l[0] + l[1] + l[2] + self.lambda_gp * pen.sum() / self.last["n_global"], gl[0] + gl[1]))
+        self.comm.allreduce(t)
+        return t
 
     # ------------------------------------------------------------------ the full step
     def full_step(self, batches, noises=None, lookahead=None, lookahead_noise=None):

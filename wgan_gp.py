@@ -188,8 +188,32 @@ def compute_gradient_penalty(discriminator, encoded_padded_real_data, fake_data,
 
 
 def _adam_hparams(optimizer):
+    """(lr, beta1, beta2, eps) of a torch.optim.Adam as built at reference :405-406; options the fused
+    Adam kernel does not implement are refused instead of being ignored."""
+    if not isinstance(optimizer, torch.optim.Adam) or type(optimizer) is not torch.optim.Adam:
+        raise S2GError(f"train_wgan drives torch.optim.Adam only (got {type(optimizer).__name__})")
+    if len(optimizer.param_groups) != 1:
+        raise S2GError("train_wgan: one parameter group per optimizer expected")
     g = optimizer.param_groups[0]
-    return g["lr"], g["betas"][0], g["betas"][1]
+    if g.get("weight_decay", 0) != 0 or g.get("amsgrad", False) or g.get("maximize", False):
+        raise S2GError("train_wgan: weight_decay / amsgrad / maximize are not supported by the fused Adam")
+    return float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"])
+
+
+def _import_adam(optimizer, module, flat_m, flat_v):
+    """Seeds the fused Adam's moments and step count from the torch optimizer's state (a second
+    train_wgan call or a resumed run continues where the optimizer stands).  Returns the step count."""
+    steps = set()
+    for name, p in module.named_parameters():
+        st = optimizer.state.get(p)
+        if not st or name not in flat_m.views:
+            continue
+        flat_m.views[name].copy_(st["exp_avg"].to(flat_m.views[name].device))
+        flat_v.views[name].copy_(st["exp_avg_sq"].to(flat_v.views[name].device))
+        steps.add(int(st["step"]))
+    if len(steps) > 1:
+        raise S2GError("train_wgan: parameters of one optimizer carry different step counts")
+    return steps.pop() if steps else 0
 
 
 def _export_adam(optimizer, module, flat_m, flat_v, step):
@@ -206,11 +230,19 @@ def train_wgan(generator, discriminator, optimizer_G, optimizer_D, train_dataloa
     device = torch.device(device)
     if device.type != "cuda":
         raise S2GError("train_wgan needs an MI355X (device 'cuda'); there is no CPU path")
-    lr, b1, b2 = _adam_hparams(optimizer_D)
-    tr = WGANGPTrainer(opt.vocab_size, generator.seq_len, device, lr=lr, b1=b1, b2=b2, lambda_gp=opt.lambda_gp,
+    lr, b1, b2, eps = _adam_hparams(optimizer_D)
+    tr = WGANGPTrainer(opt.vocab_size, generator.seq_len, device, lr=lr, b1=b1, b2=b2, eps=eps,
+                       adam_g=_adam_hparams(optimizer_G), lambda_gp=opt.lambda_gp,
                        tau=opt.tau, hard=bool(opt.hard), n_critic=opt.n_critic,
                        drop_rate=getattr(discriminator, "drop_rate", 0.3),
                        gen_engine=generator.engine(device), critic_engine=discriminator.engine(device))
+    tr.tD = _import_adam(optimizer_D, discriminator, tr.mD_named, tr.vD_named)
+    tr.tG = _import_adam(optimizer_G, generator, tr.mG_named, tr.vG_named)
+    tr.G.num_batches_tracked = int(generator.model[3].num_batches_tracked)
+
+    def sync_counters():
+        for m in (generator.model[3], generator.model[6]):
+            m.num_batches_tracked.fill_(tr.G.num_batches_tracked)
     from tqdm import tqdm
     from sklearn.metrics import f1_score
 
@@ -237,6 +269,7 @@ def train_wgan(generator, discriminator, optimizer_G, optimizer_D, train_dataloa
                     % (epoch, opt.epochs, i, len(train_dataloader), tr.d_loss().item(), tr.g_loss().item())
                 )
                 if epoch % 5 == 0:
+                    sync_counters()
                     torch.save(generator.state_dict(), f"saved_models/wgan_generator_{epoch}.pth")
                 if epoch % 5 == 0:
                     with torch.no_grad():
@@ -251,8 +284,7 @@ def train_wgan(generator, discriminator, optimizer_G, optimizer_D, train_dataloa
                         avg_f1_score = torch.mean(torch.tensor(f1_scores, dtype=torch.float32))
                         print(f"f1 score: {avg_f1_score:.4f}")
                         discriminator.train()
-    for m in (generator.model[3], generator.model[6]):
-        m.num_batches_tracked.fill_(tr.G.num_batches_tracked)
+    sync_counters()
     _export_adam(optimizer_D, discriminator, tr.mD_named, tr.vD_named, tr.tD)
     _export_adam(optimizer_G, generator, tr.mG_named, tr.vG_named, tr.tG)
     return tr
