@@ -70,6 +70,49 @@ def cpu_baseline(seconds_budget: float = 60.0):
                       f"host has {os.cpu_count()} logical CPUs, torch used {threads} threads"}
 
 
+class TimedLoader:
+    """A DataLoader stand-in for train_wgan (CPU batches shaped like collate_fn's output, custom_dataset.py:30-47):
+    drains the GPU and takes a time stamp when it hands out the first batch after the warm-up steps."""
+
+    def __init__(self, batches, warm_batches):
+        self.batches, self.warm, self.t0 = batches, warm_batches, None
+
+    def __len__(self):
+        return len(self.batches)
+
+    def __iter__(self):
+        for k, b in enumerate(self.batches):
+            if k == self.warm:
+                torch.cuda.synchronize()
+                self.t0 = time.perf_counter()
+            yield b
+
+
+def bench_train_wgan(dev, steps, warmup, device_rng, drop_rate):
+    """The drop-in path: the module surface of wgan_gp.py (Generator, Discriminator, torch.optim.Adam) driven by
+    train_wgan over a synthetic loader, exactly as main() does for real data (wgan_gp.py:393-442 of the
+    reference).  Returns (sequences/s, ms per full step) over `steps` full steps after `warmup`."""
+    import argparse as ap
+    import contextlib
+    import io
+    import common
+    import wgan_gp as W
+    opt = ap.Namespace(vocab_size=V, epochs=1, batch_size=B_PER_GPU, lr=2e-4, b1=0.5, b2=0.999, latent_dim=100, seq_len=L,
+                       n_critic=N_CRITIC, clip_value=0.01, lambda_gp=10.0, hard=False, tau=0.5, device_rng=device_rng)
+    D = W.Discriminator(V, 50, 2, 2, drop_rate=drop_rate).to(dev)
+    G = W.Generator(V, 2, seq_len=GEN_SEQ_LEN).to(dev)
+    oG = torch.optim.Adam(G.parameters(), lr=opt.lr, betas=(opt.b1, opt.b2))
+    oD = torch.optim.Adam(D.parameters(), lr=opt.lr, betas=(opt.b1, opt.b2))
+    pool = [common.batch(3000 + i, B_PER_GPU, L, vocab=V, lengths=[L] * B_PER_GPU) for i in range(2 * N_CRITIC)]
+    n = (steps + warmup) * N_CRITIC
+    loader = TimedLoader([pool[k % len(pool)] for k in range(n)], warmup * N_CRITIC)
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        W.train_wgan(G, D, oG, oD, loader, [], opt, dev)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - loader.t0
+    return steps * N_CRITIC * B_PER_GPU / dt, dt / steps * 1e3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -78,6 +121,10 @@ def main():
     ap.add_argument("--lengths", default="fixed", choices=["fixed", "adfa"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--drop-rate", type=float, default=0.3)
+    ap.add_argument("--path", default="trainer", choices=["trainer", "train_wgan"],
+                    help="which path `value` is measured on: WGANGPTrainer.full_step on device-resident batches "
+                         "(default, the headline) or the drop-in train_wgan() loop of wgan_gp.py on a CPU loader; "
+                         "the other one is reported beside it on one GPU")
     a = ap.parse_args()
 
     from s2g import lib
@@ -111,12 +158,11 @@ def main():
 
     import common
     tr = WGANGPTrainer(V, GEN_SEQ_LEN, dev, lr=2e-4, b1=0.5, b2=0.999, lambda_gp=10.0, tau=0.5, hard=False,
-                       n_critic=N_CRITIC, drop_rate=a.drop_rate, comm=comm)
+                       n_critic=N_CRITIC, drop_rate=a.drop_rate, comm=comm, seed=42 + rank)   # per-rank noise streams
     if os.environ.get("S2G_NO_OVERLAP") == "1":
         tr.D.overlap = False                                      # one stream, launch after launch (debugging aid)
     tr.G.load(common.generator_params(801, V, GEN_SEQ_LEN))      # same initial weights on every rank
     tr.D.load(common.critic_params(802, vocab=V))
-    torch.manual_seed(42 + rank)                                  # per-rank noise streams
     pool = make_batches(1000 + 7919 * rank, 2 * N_CRITIC, B_PER_GPU, dev, a.lengths)
     if comm is not None:
         from s2g.parallel import global_wsum
@@ -230,6 +276,18 @@ def main():
             "kernels": kernels, "launch_avg_ms": launches,
             "second_stream": ("cu-masked, 3/4 of the CUs" if tr.D._side else None),
         }
+        if world == 1:
+            # the drop-in path (python3 wgan_gp.py ..., README.md:83): same step through train_wgan() and the nn.Module
+            # surface, batches arriving from a CPU loader; with device-side draws, and with the reference-compatible
+            # draws on the CPU generator (z, Gumbel uniforms, alpha: 2 x 23 MB of torch.rand + copies per batch)
+            v_dev, ms_dev = bench_train_wgan(dev, a.steps, a.warmup, True, a.drop_rate)
+            v_cpu, ms_cpu = bench_train_wgan(dev, 2, 1, False, a.drop_rate)
+            line["train_wgan_path"] = {"value": v_dev, "unit": "sequences/s", "ms_per_step": ms_dev, "rng": "device (--device_rng)",
+                                       "reference_compatible_cpu_rng": {"value": v_cpu, "ms_per_step": ms_cpu, "steps": 2}}
+            if a.path == "train_wgan":
+                line["trainer_path"] = {"value": line["value"], "ms_per_step": line["ms_per_step"]}
+                line["value"], line["ms_per_step"] = v_dev, ms_dev
+                line["config"]["workload"] += "; measured through train_wgan() on a CPU loader with --device_rng"
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

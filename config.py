@@ -23,6 +23,9 @@ def get_args(argv=None):
     parser.add_argument("--gen_seq_len", type=int, default=120,
                         help="generator sequence length (the reference hard-codes 120)")
     parser.add_argument("--drop_rate", type=float, default=0.3, help="critic LSTM inter-layer dropout")
+    parser.add_argument("--device_rng", action="store_true",
+                        help="draw z / Gumbel uniforms / alpha on the GPU (faster; the default draws them on the "
+                             "CPU generator in the reference's order, so a seed reproduces the reference's noise)")
 
     opt = parser.parse_args(argv)
     print(opt)

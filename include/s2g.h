@@ -45,6 +45,16 @@ typedef struct S2GSeq {
 int s2g_gumbel_softmax_fwd(const float* logits, const float* U, const float* bias, int bias_rows,
                            float* y_out, float* y_soft, long rows, int V, float tau, int mode, int hard,
                            void* stream);
+/* mode 0 with the uniforms drawn inside the kernel (Philox4x32-10 keyed by `seed`; element (row, 4l..4l+3)
+ * takes the four outputs of counter (row * 64 + l, offset)): replaces torch.rand(logits.size()).to(device)
+ * of wgan_gp.py:58 without a [rows, V] tensor of draws.  A draw is a pure function of (seed, offset,
+ * position); the caller advances offset by one per launch.  V <= 256. */
+int s2g_gumbel_softmax_fwd_rng(const float* logits, const float* bias, int bias_rows, float* y_out, float* y_soft,
+                               long rows, int V, float tau, int hard, unsigned long long seed,
+                               unsigned long long offset, void* stream);
+/* out[0..n) = uniform [0,1) draws (kind 0: torch.rand, wgan_gp.py:228) or standard normal draws (kind 1:
+ * torch.randn, :291) from the same counter-based generator. */
+int s2g_rng_fill(float* out, long n, int kind, unsigned long long seed, unsigned long long offset, void* stream);
 /* autograd of the above: dlogits = scale * y * (dy - <dy, y>), scale = 1/tau (modes 0,1) or 1. */
 int s2g_gumbel_softmax_bwd(const float* y_soft, const float* dy, float* dlogits, long rows, int V,
                            float scale, void* stream);
@@ -245,6 +255,9 @@ int s2g_lrelu_bwd(const float* y, float* dy, long n, void* stream);
 /* inter-layer dropout of nn.LSTM(175, 50, 2, dropout=p) in train mode (wgan_gp.py:189): uniform draws
  * u[rows][52] -> multiplier (u >= p) / (1 - p) in place, columns 50 and 51 (row padding) -> 0 */
 int s2g_dropout_mask(float* u, long rows, float p, void* stream);
+/* the same mask [rows][52] with the uniforms drawn inside the kernel (one write pass, no tensor of draws) */
+int s2g_dropout_mask_rng(float* mask, long rows, float p, unsigned long long seed, unsigned long long offset,
+                         void* stream);
 int s2g_bn_stats(const float* x, float* stats, int B, int F, void* stream);
 int s2g_bn_lrelu_apply(const float* x, const float* stats, float n_global, const float* gamma,
                        const float* beta, float* run_mean, float* run_var, float eps, float momentum,

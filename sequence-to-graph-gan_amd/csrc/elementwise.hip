@@ -260,33 +260,67 @@ extern "C" __global__ void s2g_k_pack_critic(const float* __restrict__ wih0, con
 }
 
 // x[r][v] = (tokens[r] == v), rows beyond the sequence's length are zero      (wgan_gp.py:277)
+// Each thread owns four consecutive floats of the flat [rows * V] output (one 16-byte store; the group may
+// straddle two rows, so the row / column pair is stepped per element).
 extern "C" __global__ void s2g_k_one_hot(const int* __restrict__ tokens, const int* __restrict__ lengths, int T,
                                          float* __restrict__ x, long rows, int V) {
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= rows * V) return;
+  const long i = 4 * ((long)blockIdx.x * blockDim.x + threadIdx.x);
+  const long n = rows * V;
+  if (i >= n) return;
   long r = i / V;
-  int v = (int)(i % V);
-  bool live = lengths ? (int)(r % T) < lengths[r / T] : true;
-  x[i] = (live && min(max(tokens[r], 0), V - 1) == v) ? 1.0f : 0.0f;      // ids clamped as in the forward sweep
+  int v = (int)(i - r * V);
+  float o[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    o[k] = 0.0f;
+    if (i + k < n) {
+      const bool live = lengths ? (int)(r % T) < lengths[r / T] : true;
+      o[k] = (live && min(max(tokens[r], 0), V - 1) == v) ? 1.0f : 0.0f;      // ids clamped as in the forward sweep
+    }
+    if (++v == V) { v = 0; ++r; }
+  }
+  if (i + 3 < n) *reinterpret_cast<float4*>(x + i) = make_float4(o[0], o[1], o[2], o[3]);
+  else
+    for (int k = 0; i + k < n; ++k) x[i + k] = o[k];
 }
 
 // x_hat[b][t][v] = alpha_b * onehot(tok[b][t])[v] + (1 - alpha_b) * fake[b][t][v] (0 for t >= Tf)
 // (wgan_gp.py:231-239); rows t >= len_b are written as zero (packing drops them, :241).
+// Four consecutive floats per thread; with Tf == T the fake batch has the output's own flat layout and
+// is read with one 16-byte load.
 extern "C" __global__ void s2g_k_gp_interp(const int* __restrict__ tokens, const int* __restrict__ lengths,
                                            const float* __restrict__ fake, const float* __restrict__ alpha, int B,
                                            int T, int Tf, int V, float* __restrict__ xhat) {
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long)B * T * V) return;
-  int v = (int)(i % V);
+  const long i = 4 * ((long)blockIdx.x * blockDim.x + threadIdx.x);
+  const long n = (long)B * T * V;
+  if (i >= n) return;
   long r = i / V;
-  int t = (int)(r % T), b = (int)(r / T);
-  float out = 0.0f;
-  if (t < lengths[b]) {
-    float a = alpha[b];
-    float f = (t < Tf) ? fake[((long)b * Tf + t) * V + v] : 0.0f;
-    out = (min(max(tokens[r], 0), V - 1) == v ? a : 0.0f) + (1.0f - a) * f;
+  int v = (int)(i - r * V);
+  const bool full = i + 3 < n;
+  float f[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool same = Tf == T;
+  if (same && full) {
+    const float4 q = *reinterpret_cast<const float4*>(fake + i);
+    f[0] = q.x; f[1] = q.y; f[2] = q.z; f[3] = q.w;
   }
-  xhat[i] = out;
+  float o[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    o[k] = 0.0f;
+    if (i + k < n) {
+      const int t = (int)(r % T), b = (int)(r / T);
+      if (t < lengths[b]) {
+        const float a = alpha[b];
+        float fk = f[k];
+        if (!(same && full)) fk = (t < Tf) ? fake[((long)b * Tf + t) * V + v] : 0.0f;
+        o[k] = (min(max(tokens[r], 0), V - 1) == v ? a : 0.0f) + (1.0f - a) * fk;
+      }
+    }
+    if (++v == V) { v = 0; ++r; }
+  }
+  if (full) *reinterpret_cast<float4*>(xhat + i) = make_float4(o[0], o[1], o[2], o[3]);
+  else
+    for (int k = 0; i + k < n; ++k) xhat[i + k] = o[k];
 }
 
 // Gradient-penalty reduction (wgan_gp.py:255-256) fused with the scaling that seeds the
@@ -304,10 +338,24 @@ extern "C" __global__ __launch_bounds__(1024) void s2g_k_gp_norm_penalty(float* 
   float s = 0.0f;
   // 16-byte accesses only when every sample starts 16-byte aligned
   const long n4 = (per_sample & 3) == 0 ? (per_sample >> 2) : 0;
-  for (long i = threadIdx.x; i < n4; i += blockDim.x) {
+  // four independent 16-byte loads in flight per thread: one workgroup per sample leaves most CUs idle, so
+  // each workgroup has to keep its own share of the memory pipeline full
+  float s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+  long i = threadIdx.x;
+  for (; i + 3 * (long)blockDim.x < n4; i += 4 * (long)blockDim.x) {
+    const float4 a = reinterpret_cast<const float4*>(gb)[i], b4 = reinterpret_cast<const float4*>(gb)[i + blockDim.x];
+    const float4 c = reinterpret_cast<const float4*>(gb)[i + 2 * blockDim.x];
+    const float4 d = reinterpret_cast<const float4*>(gb)[i + 3 * blockDim.x];
+    s = fmaf(a.x, a.x, s); s = fmaf(a.y, a.y, s); s = fmaf(a.z, a.z, s); s = fmaf(a.w, a.w, s);
+    s1 = fmaf(b4.x, b4.x, s1); s1 = fmaf(b4.y, b4.y, s1); s1 = fmaf(b4.z, b4.z, s1); s1 = fmaf(b4.w, b4.w, s1);
+    s2 = fmaf(c.x, c.x, s2); s2 = fmaf(c.y, c.y, s2); s2 = fmaf(c.z, c.z, s2); s2 = fmaf(c.w, c.w, s2);
+    s3 = fmaf(d.x, d.x, s3); s3 = fmaf(d.y, d.y, s3); s3 = fmaf(d.z, d.z, s3); s3 = fmaf(d.w, d.w, s3);
+  }
+  for (; i < n4; i += blockDim.x) {
     float4 v = reinterpret_cast<const float4*>(gb)[i];
     s = fmaf(v.x, v.x, s); s = fmaf(v.y, v.y, s); s = fmaf(v.z, v.z, s); s = fmaf(v.w, v.w, s);
   }
+  s = (s + s1) + (s2 + s3);
   for (long i = (n4 << 2) + threadIdx.x; i < per_sample; i += blockDim.x) s = fmaf(gb[i], gb[i], s);
   s = row16_sum(s);
   s += __shfl_xor(s, 16);

@@ -24,16 +24,50 @@ int s2g_gumbel_softmax_fwd(const float* logits, const float* U, const float* bia
   if (mode != 2 && !(tau > 0.0f)) return -1;
   if (hard && !y_soft) return -1;
   if (bias && bias_rows <= 0) return -1;
-  hipLaunchKernelGGL(s2g_k_gumbel_softmax_fwd, dim3(cdiv(rows, 4)), dim3(256), 0, ST(stream), logits, U, bias,
-                     bias_rows, y_out, y_soft, rows, V, 1.0f / tau, mode, hard);
+  if (V <= 256)
+    hipLaunchKernelGGL(s2g_k_gumbel_softmax_fwd_v4<false>, dim3(cdiv(rows, 4)), dim3(256), 0, ST(stream), logits, U,
+                       bias, bias_rows, y_out, y_soft, rows, V, 1.0f / tau, mode, hard, 0ULL, 0ULL);
+  else
+    hipLaunchKernelGGL(s2g_k_gumbel_softmax_fwd, dim3(cdiv(rows, 4)), dim3(256), 0, ST(stream), logits, U, bias,
+                       bias_rows, y_out, y_soft, rows, V, 1.0f / tau, mode, hard);
+  return LAUNCH_OK();
+}
+
+int s2g_gumbel_softmax_fwd_rng(const float* logits, const float* bias, int bias_rows, float* y_out, float* y_soft,
+                               long rows, int V, float tau, int hard, unsigned long long seed,
+                               unsigned long long offset, void* stream) {
+  if (!logits || !y_out || rows <= 0 || V <= 0 || V > 256 || !(tau > 0.0f)) return -1;
+  if (hard && !y_soft) return -1;
+  if (bias && bias_rows <= 0) return -1;
+  hipLaunchKernelGGL(s2g_k_gumbel_softmax_fwd_v4<true>, dim3(cdiv(rows, 4)), dim3(256), 0, ST(stream), logits,
+                     (const float*)nullptr, bias, bias_rows, y_out, y_soft, rows, V, 1.0f / tau, 0, hard, seed, offset);
+  return LAUNCH_OK();
+}
+
+int s2g_rng_fill(float* out, long n, int kind, unsigned long long seed, unsigned long long offset, void* stream) {
+  if (!out || n <= 0 || (kind != 0 && kind != 1)) return -1;
+  hipLaunchKernelGGL(s2g_k_rng_fill, dim3(cdiv((n + 3) / 4, 256)), dim3(256), 0, ST(stream), out, n, kind, seed, offset);
+  return LAUNCH_OK();
+}
+
+int s2g_dropout_mask_rng(float* mask, long rows, float p, unsigned long long seed, unsigned long long offset,
+                         void* stream) {
+  if (!mask || rows <= 0 || !(p >= 0.0f) || !(p < 1.0f) || ((uintptr_t)mask & 15)) return -1;
+  const long n4 = rows * (S2G_MASKW / 4);
+  hipLaunchKernelGGL(s2g_k_dropout_mask_rng, dim3(cdiv(n4, 256)), dim3(256), 0, ST(stream), mask, n4, p,
+                     1.0f / (1.0f - p), seed, offset);
   return LAUNCH_OK();
 }
 
 int s2g_gumbel_softmax_bwd(const float* y_soft, const float* dy, float* dlogits, long rows, int V, float scale,
                            void* stream) {
   if (!y_soft || !dy || !dlogits || rows <= 0 || V <= 0 || V > 64 * MAXPER) return -1;
-  hipLaunchKernelGGL(s2g_k_gumbel_softmax_bwd, dim3(cdiv(rows, 4)), dim3(256), 0, ST(stream), y_soft, dy,
-                     dlogits, rows, V, scale);
+  if (V <= 256)
+    hipLaunchKernelGGL(s2g_k_gumbel_softmax_bwd_v4, dim3(cdiv(rows, 4)), dim3(256), 0, ST(stream), y_soft, dy, dlogits,
+                       rows, V, scale);
+  else
+    hipLaunchKernelGGL(s2g_k_gumbel_softmax_bwd, dim3(cdiv(rows, 4)), dim3(256), 0, ST(stream), y_soft, dy,
+                       dlogits, rows, V, scale);
   return LAUNCH_OK();
 }
 
@@ -342,15 +376,17 @@ int s2g_generator_loss(const float* out, const long long* labels, int B, float i
 
 int s2g_one_hot(const int* tokens, const int* lengths, int T, float* x, long rows, int V, void* stream) {
   if (!tokens || !x || rows <= 0 || V <= 0 || (lengths && T <= 0)) return -1;
-  hipLaunchKernelGGL(s2g_k_one_hot, dim3(cdiv(rows * V, 256)), dim3(256), 0, ST(stream), tokens, lengths, T, x,
+  if (((uintptr_t)x) & 15) return -1;
+  hipLaunchKernelGGL(s2g_k_one_hot, dim3(cdiv(cdiv(rows * V, 4), 256)), dim3(256), 0, ST(stream), tokens, lengths, T, x,
                      rows, V);
   return LAUNCH_OK();
 }
 int s2g_gp_interp(const int* tokens, const int* lengths, const float* fake, const float* alpha, int B, int T,
                   int Tf, int V, float* xhat, void* stream) {
   if (!tokens || !lengths || !fake || !alpha || !xhat || B <= 0 || T <= 0 || Tf <= 0 || V <= 0) return -1;
-  hipLaunchKernelGGL(s2g_k_gp_interp, dim3(cdiv((long)B * T * V, 256)), dim3(256), 0, ST(stream), tokens, lengths,
-                     fake, alpha, B, T, Tf, V, xhat);
+  if ((((uintptr_t)xhat) | ((uintptr_t)fake)) & 15) return -1;
+  hipLaunchKernelGGL(s2g_k_gp_interp, dim3(cdiv(cdiv((long)B * T * V, 4), 256)), dim3(256), 0, ST(stream), tokens,
+                     lengths, fake, alpha, B, T, Tf, V, xhat);
   return LAUNCH_OK();
 }
 int s2g_gp_norm_penalty(float* g, int B, long per_sample, float upstream, float n_batch, float* pen, float* norms,

@@ -2,6 +2,7 @@
 // wgan_gp.py:36-104).  One 64-lane wavefront per row of V logits (V = 175 -> 3 values per
 // lane); max and sum are reduced with DPP inside each 16-lane row and two cross-row shuffles.
 #include "s2g_common.h"
+#include "rng.hip"
 
 #define MAXPER 8   // supports V <= 512
 
@@ -113,6 +114,118 @@ extern "C" __global__ __launch_bounds__(256) void s2g_k_gumbel_softmax_bwd(
     int j = lane + 64 * e;
     if (j < V) dlogits[row * V + j] = scale * yv[e] * (dv[e] - dot);
   }
+}
+
+// ---- 16-byte form for V <= 256 (the 175-way vocabulary): lane l owns columns 4l..4l+3 of its row and
+// moves them with one 16-byte access (rows of 175 floats are only 4-byte aligned; the memory pipeline
+// takes 16-byte accesses at any 4-byte address), so a row is 44 requests instead of 175.  With RNG the
+// Gumbel uniforms come from Philox (one call per lane = its four columns) instead of a [rows, V] tensor
+// of draws: no 4 bytes per element written by a generator kernel and read back here.
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+
+__device__ __forceinline__ void load4(const float* p, int nv, float fill, float out[4]) {
+  if (nv >= 4) {
+    const f4u v = *reinterpret_cast<const f4u*>(p);
+    out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[k] = k < nv ? p[k] : fill;
+  }
+}
+__device__ __forceinline__ void store4(float* p, int nv, const float v[4]) {
+  if (nv >= 4) {
+    *reinterpret_cast<f4u*>(p) = (f4u){v[0], v[1], v[2], v[3]};
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < nv) p[k] = v[k];
+  }
+}
+
+template <bool RNG>
+__global__ __launch_bounds__(256) void s2g_k_gumbel_softmax_fwd_v4(
+    const float* __restrict__ logits, const float* __restrict__ U, const float* __restrict__ bias, int bias_rows,
+    float* __restrict__ y_out, float* __restrict__ y_soft, long rows, int V, float inv_tau, int mode, int hard,
+    unsigned long long seed, unsigned long long offset) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int j0 = 4 * lane, nv = V - j0;          // nv >= 4: four live columns, 1..3: the row's tail, <= 0: none
+  const long base = row * V + j0;
+  float z[4], u[4];
+  load4(logits + base, nv, -INFINITY, z);
+  if (bias) {
+    float b[4];
+    load4(bias + (row % bias_rows) * V + j0, nv, 0.0f, b);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) z[k] += b[k];
+  }
+  if (mode == 0) {
+    if (RNG) {
+      const Philox4 r = philox4x32_10((unsigned long long)row * 64 + lane, offset, seed);
+      u[0] = u01(r.x); u[1] = u01(r.y); u[2] = u01(r.z); u[3] = u01(r.w);
+    } else {
+      load4(U + base, nv, 0.5f, u);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float uu = 1e-10f + (1.0f - 1e-10f) * u[k];
+      z[k] += -logf(-logf(uu + 1e-20f) + 1e-20f);
+    }
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    z[k] = k < nv ? ((mode == 2) ? z[k] : z[k] * inv_tau) : -INFINITY;
+    mx = fmaxf(mx, z[k]);
+  }
+  mx = wave_max(mx);
+  float sum = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    z[k] = k < nv ? expf(z[k] - mx) : 0.0f;
+    sum += z[k];
+  }
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum;
+  float pr[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) pr[k] = z[k] * inv;
+  if (y_soft) store4(y_soft + base, nv, pr);
+  if (hard) {
+    float bv = -1.0f;
+    int best = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < nv && pr[k] > bv) { bv = pr[k]; best = j0 + k; }
+    const float wm = wave_max(bv);
+    int cand = (bv == wm) ? best : 0x7fffffff;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) cand = min(cand, __shfl_xor(cand, o));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pr[k] = (j0 + k == cand) ? 1.0f : 0.0f;
+  }
+  store4(y_out + base, nv, pr);
+}
+
+extern "C" __global__ __launch_bounds__(256) void s2g_k_gumbel_softmax_bwd_v4(
+    const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dlogits, long rows, int V,
+    float scale) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int j0 = 4 * lane, nv = V - j0;
+  const long base = row * V + j0;
+  float yv[4], dv[4];
+  load4(y + base, nv, 0.0f, yv);
+  load4(dy + base, nv, 0.0f, dv);
+  float dot = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) dot = fmaf(yv[k], dv[k], dot);
+  dot = wave_sum(dot);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) dv[k] = scale * yv[k] * (dv[k] - dot);
+  store4(dlogits + base, nv, dv);
 }
 
 // tokens[row] = argmax_j y[row][j]  (generate_fake_data.py:66), first maximal index.

@@ -79,7 +79,7 @@ class CriticEngine:
                                            # queue) of its own, so the prefetch hook shares the second stream instead
         self._m2_events = None        # (weights packed, M2 built) when M2 is built on a side stream
         self._m2_pending = False
-        self._ws_key = None
+        self._ws_cache = {}           # (nseq, Tw, so_seqs) -> workspace; batches of a few shapes alternate in an epoch
         self.ws: Dict[str, torch.Tensor] = {}
 
     # ------------------------------------------------------------------ parameters
@@ -174,10 +174,18 @@ class CriticEngine:
         second-order buffers.  Zero-initialised once: rows beyond a sequence's length keep finite
         stale values and are only ever multiplied by zero-filled gate gradients."""
         key = (nseq, Tw, so_seqs)
-        if self._ws_key == key:
-            return self.ws
-        self.ws, self._ws_key = self.fresh_workspace(nseq, Tw, so_seqs), key
-        return self.ws
+        ws = self._ws_cache.get(key)
+        if ws is None:
+            # a ragged last batch or a batch whose longest sequence is shorter comes back every epoch: keep
+            # a few shapes (most recently used last) instead of re-allocating and zero-filling ~0.8 GB each time
+            while len(self._ws_cache) >= 4:
+                self._ws_cache.pop(next(iter(self._ws_cache)))
+            ws = self.fresh_workspace(nseq, Tw, so_seqs)
+        else:
+            self._ws_cache.pop(key)
+        self._ws_cache[key] = ws
+        self.ws = ws
+        return ws
 
     def fresh_workspace(self, nseq: int, Tw: int, so_seqs: int) -> Dict[str, torch.Tensor]:
         """A private set of buffers (the autograd bridges keep one per outstanding forward)."""

@@ -51,6 +51,7 @@ class GeneratorEngine:
         self.scratch = ops.Scratch(device)
         self.saved: Dict[str, torch.Tensor] = {}
         self.last_layer_ready: Optional[torch.cuda.Event] = None   # set while that layer's update is in flight
+        self.rng = ops.DeviceRng()      # Gumbel uniforms of forwards that are not handed a tensor of draws
 
     def load(self, state: Dict[str, torch.Tensor]) -> None:
         for k, v in self.params.views.items():
@@ -111,16 +112,15 @@ class GeneratorEngine:
             self.num_batches_tracked += 1
         logits = torch.empty(B, self.L * self.V, device=dev)
         mode = ops.MODES.get(act, 2)
-        if mode == 0 and U is None:
-            U = torch.rand(B, self.L, self.V, device=dev)      # noise draw only; the sampler is the kernel
         if heavy_after is not None:
             heavy_after()
         if self.last_layer_ready is not None:
             # the output Linear's update may still be running on another stream (trainer._generator_step)
             torch.cuda.current_stream().wait_event(self.last_layer_ready)
         ops.linear_fwd_small_batch(a3, p["model.8.weight"], p["model.8.bias"], logits, workgroups)
+        # (U None in the Gumbel mode: the sampler draws its uniforms itself, wgan_gp.py:58)
         y, y_soft = ops.gumbel_softmax_fwd(logits.view(B, self.L, self.V), U if mode == 0 else None, tau, mode,
-                                           hard, out=out)
+                                           hard, out=out, rng=self.rng)
         if save:
             self.saved = dict(z=z, labels=labels, x0=x0, a1=a1, a2=a2, xhat2=xhat2, inv2=inv2, a3=a3, xhat3=xhat3,
                               inv3=inv3, y_soft=y_soft, scale=(1.0 if mode == 2 else 1.0 / tau), B=B)

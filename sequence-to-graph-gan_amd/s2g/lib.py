@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # S2G_LIB points kernel-tuning tools at an alternative build of the same library
 LIB_PATH = os.environ.get("S2G_LIB") or os.path.join(_HERE, "libs2g.so")
 
-P, I, L, F = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
+P, I, L, F, U64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_uint64
 
 
 class S2GSeq(ctypes.Structure):
@@ -49,6 +49,9 @@ class S2GCriticUpdate(ctypes.Structure):
 SIGNATURES = {
     "s2g_version": [],
     "s2g_gumbel_softmax_fwd": [P, P, P, I, P, P, L, I, F, I, I, P],
+    "s2g_gumbel_softmax_fwd_rng": [P, P, I, P, P, L, I, F, I, U64, U64, P],
+    "s2g_rng_fill": [P, L, I, U64, U64, P],
+    "s2g_dropout_mask_rng": [P, L, F, U64, U64, P],
     "s2g_gumbel_softmax_bwd": [P, P, P, L, I, F, P],
     "s2g_argmax_rows": [P, P, L, I, P],
     "s2g_gemm_f32": [ctypes.POINTER(S2GGemm), I, P],

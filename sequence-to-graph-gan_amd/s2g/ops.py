@@ -156,13 +156,47 @@ def colsum(X: torch.Tensor, rows: int, cols: int, ld: int, out: torch.Tensor, sc
         reduce_slabs(part, cols, nch, 1, cols, out, accumulate=accumulate)
 
 
+# ----------------------------------------------------------------------------- random draws
+class DeviceRng:
+    """Seed and running offset of the library's counter-based generator (Philox4x32-10): every draw is a
+    pure function of (seed, offset, position) and takes the next offset, so no generator state lives on
+    the device.  Stands in for the reference's CPU-generator draws (wgan_gp.py:58, 228, 291), which no
+    device generator reproduces; parity runs inject their noise instead."""
+
+    def __init__(self, seed: Optional[int] = None):
+        self.seed = (torch.initial_seed() if seed is None else int(seed)) & 0xFFFFFFFFFFFFFFFF
+        self.offset = 0
+
+    def take(self):
+        o = self.offset
+        self.offset += 1
+        return self.seed, o
+
+
+def rng_fill(out: torch.Tensor, kind: int, rng: DeviceRng) -> torch.Tensor:
+    """out <- uniform [0,1) (kind 0) or standard normal (kind 1) draws."""
+    _chk(out, name="out")
+    seed, off = rng.take()
+    call("s2g_rng_fill", ptr(out), out.numel(), kind, seed, off, stream_ptr())
+    return out
+
+
+def dropout_mask_rng(rows: int, p: float, device, rng: DeviceRng) -> torch.Tensor:
+    """[rows, 52] multipliers (0 or 1/(1-p); columns 50, 51 zero) of the critic's inter-layer dropout."""
+    m = torch.empty(rows, MASKW, device=device)
+    seed, off = rng.take()
+    call("s2g_dropout_mask_rng", ptr(m), rows, float(p), seed, off, stream_ptr())
+    return m
+
+
 # ----------------------------------------------------------------------------- sampler
 MODES = {"gumbel_softmax": 0, "relaxed_bernoulli": 1}
 
 
 def gumbel_softmax_fwd(logits: torch.Tensor, U: Optional[torch.Tensor], tau: float, mode: int, hard: bool,
                        bias: Optional[torch.Tensor] = None, bias_rows: int = 0,
-                       out: Optional[torch.Tensor] = None):
+                       out: Optional[torch.Tensor] = None, rng: Optional[DeviceRng] = None):
+    """rng (mode 0 with U None): the uniforms are drawn inside the kernel."""
     _chk(logits, name="logits")
     V = logits.shape[-1]
     rows = logits.numel() // V
@@ -176,6 +210,13 @@ def gumbel_softmax_fwd(logits: torch.Tensor, U: Optional[torch.Tensor], tau: flo
             raise S2GError("gumbel_softmax: out must have the size of logits")
     y = out.view_as(logits) if out is not None else torch.empty_like(logits)
     y_soft = torch.empty_like(logits) if hard else None
+    if mode == 0 and U is None:
+        if rng is None:
+            raise S2GError("gumbel_softmax: the Gumbel mode needs the uniforms U or a DeviceRng")
+        seed, off = rng.take()
+        call("s2g_gumbel_softmax_fwd_rng", ptr(logits), ptr(bias), bias_rows, ptr(y), ptr(y_soft), rows, V, float(tau),
+             int(hard), seed, off, stream_ptr())
+        return y, (y_soft if hard else y)
     call("s2g_gumbel_softmax_fwd", ptr(logits), ptr(U), ptr(bias), bias_rows, ptr(y), ptr(y_soft), rows, V,
          float(tau), mode, int(hard), stream_ptr())
     return y, (y_soft if hard else y)

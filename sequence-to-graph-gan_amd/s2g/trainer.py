@@ -25,23 +25,22 @@ def class_weight_sum(labels_cpu: torch.Tensor) -> float:
     return CLASS_W[0] * (labels_cpu.numel() - n1) + CLASS_W[1] * n1
 
 
-def dropout_mask(rows: int, p: float, device) -> Optional[torch.Tensor]:
+def dropout_mask(rows: int, p: float, device, rng: ops.DeviceRng) -> Optional[torch.Tensor]:
     """[rows, 52] multiplier (0 or 1/(1-p)) for the layer-0 outputs, as nn.LSTM(dropout=p) applies
     in train mode (wgan_gp.py:189); columns 50,51 are padding."""
     if p <= 0.0:
         return None
-    m = torch.rand(rows, MASKW, device=device)          # the draw; the thresholding is one libs2g kernel
-    call("s2g_dropout_mask", ptr(m), rows, float(p), stream_ptr())
-    return m
+    return ops.dropout_mask_rng(rows, p, device, rng)
 
 
 class WGANGPTrainer:
     def __init__(self, vocab: int, gen_seq_len: int, device, lr: float = 2e-4, b1: float = 0.5, b2: float = 0.999,
                  lambda_gp: float = 10.0, tau: float = 0.5, hard: bool = False, n_critic: int = 5,
                  drop_rate: float = 0.3, comm=None, gen_engine=None, critic_engine=None, eps: float = 1e-8,
-                 adam_g=None):
+                 adam_g=None, seed: Optional[int] = None):
         """lr, b1, b2, eps: Adam hyper-parameters of the critic's optimizer (wgan_gp.py:406) and, unless
-        adam_g = (lr, b1, b2, eps) says otherwise, of the generator's (wgan_gp.py:405)."""
+        adam_g = (lr, b1, b2, eps) says otherwise, of the generator's (wgan_gp.py:405).
+        seed: seed of the device-side draws (z, Gumbel uniforms, alpha, dropout masks) that are not injected."""
         self.device = torch.device(device)
         self.comm = comm or NoComm()
         self.G = gen_engine or GeneratorEngine(vocab, gen_seq_len, self.device, comm=self.comm)
@@ -53,6 +52,9 @@ class WGANGPTrainer:
         self.adam_g = tuple(adam_g) if adam_g is not None else (lr, b1, b2, eps)
         self.lambda_gp, self.tau, self.hard, self.n_critic, self.drop_rate = lambda_gp, tau, hard, n_critic, drop_rate
         self.V, self.L = vocab, gen_seq_len
+        if seed is not None:
+            self.G.rng = ops.DeviceRng(seed)      # default: torch.initial_seed() when the engine was built
+        self.rng = self.G.rng           # one stream of draws: z, Gumbel uniforms, alpha, dropout masks
         self.mD_named, self.vD_named = self.D.params.like(), self.D.params.like()   # Adam moments (named views)
         self.mG_named, self.vG_named = self.G.params.like(), self.G.params.like()
         self.mD, self.vD = self.mD_named.flat, self.vD_named.flat
@@ -105,6 +107,13 @@ class WGANGPTrainer:
             yield
         cur.wait_stream(own)
 
+    def stream(self):
+        """Context for a caller's whole loop: everything enqueued inside (the steps, but also the caller's own
+        host-to-device copies) goes to the trainer's non-blocking stream.  A copy issued on the NULL stream
+        would wait for the CU-masked streams (blocking streams) to drain, i.e. stall the host behind the step
+        that is still running."""
+        return self._own_stream()
+
     def critic_step(self, *args, **kwargs):
         """One critic update (wgan_gp.py:277-318); arguments of _critic_step."""
         with self._own_stream():
@@ -150,15 +159,15 @@ class WGANGPTrainer:
             if pre is not None:
                 torch.cuda.current_stream().wait_event(pre["done"])     # keep the generator's buffer updates ordered
             if z is None:
-                z = torch.randn(B, LATENT, device=dev)
+                z = ops.rng_fill(torch.empty(B, LATENT, device=dev), 1, self.rng)
             fake = self.G.forward(z, labels, U, self.tau, self.hard, training=True, save=False,
                                   out=self._fake_buf(self._fake_cur, B))    # .detach(): no graph is kept
             self._join_generator(waited=True)     # the forward waited for a pending output-layer update
         if alpha is None:
-            alpha = torch.rand(B, device=dev)
+            alpha = ops.rng_fill(torch.empty(B, device=dev), 0, self.rng)
         Tw = max(T, self.L)
         if mask is None and self.drop_rate > 0.0:
-            mask = dropout_mask(3 * B * Tw, self.drop_rate, dev)
+            mask = dropout_mask(3 * B * Tw, self.drop_rate, dev, self.rng)
         prefetch = None
         # (with several ranks the prefetched forwards issue their BatchNorm all-reduces from the second stream;
         # every rank runs the same host code, so all ranks issue their collectives in the same order)
@@ -168,7 +177,7 @@ class WGANGPTrainer:
 
             def prefetch(heavy_after=None):
                 if nxt["z"] is None:        # drawn on the prefetch stream: nothing of it sits on the caller's
-                    nxt["z"] = torch.randn(B, LATENT, device=dev)
+                    nxt["z"] = ops.rng_fill(torch.empty(B, LATENT, device=dev), 1, self.rng)
                 self.G.forward(nxt["z"], nxt["labels"], next_batch.get("U"), self.tau, self.hard, training=True,
                                save=False, out=other, heavy_after=heavy_after, workgroups=self.D.cu_masked)
                 nxt["done"].record()
@@ -176,9 +185,9 @@ class WGANGPTrainer:
             def idle():
                 # the next step's own draws, made while this stream waits for the second-order sweeps
                 if next_batch.get("alpha") is None:
-                    nxt["alpha"] = torch.rand(B, device=dev)
+                    nxt["alpha"] = ops.rng_fill(torch.empty(B, device=dev), 0, self.rng)
                 if next_batch.get("mask") is None and self.drop_rate > 0.0 and next_batch.get("T"):
-                    nxt["mask"] = dropout_mask(3 * B * max(next_batch["T"], self.L), self.drop_rate, dev)
+                    nxt["mask"] = dropout_mask(3 * B * max(next_batch["T"], self.L), self.drop_rate, dev, self.rng)
                 if nxt.get("alpha") is not None and next_batch.get("lengths") is not None and next_batch.get("T"):
                     # the next batch's sequence descriptors too (two buffers: this batch's are still in use)
                     self._desc_cur ^= 1
@@ -199,7 +208,7 @@ class WGANGPTrainer:
 
             def idle():
                 if gen_next.get("mask") is None and self.drop_rate > 0.0:
-                    gp["mask"] = dropout_mask(B * self.L, self.drop_rate, dev)
+                    gp["mask"] = dropout_mask(B * self.L, self.drop_rate, dev, self.rng)
         else:
             idle = None
         # one process: the final slab reduction, Adam and the weight repack run as one launch
@@ -253,7 +262,7 @@ class WGANGPTrainer:
         else:
             fake = self.G.forward(z, labels, U, self.tau, self.hard, training=True, save=True)
         if mask is None and self.drop_rate > 0.0:
-            mask = dropout_mask(B * self.L, self.drop_rate, self.device)
+            mask = dropout_mask(B * self.L, self.drop_rate, self.device, self.rng)
         losses, dfake = critic_forward_backward_fake(self.D, fake, labels, n_global, 1.0 / wsum, mask, CLASS_W)
         side = self.D.side() if (update and self.D.overlap) else None
         if side is None:

@@ -5,7 +5,7 @@ the fixtures it writes are data: inputs are regenerated from seeds by tests/gold
 expected outputs come from the unmodified reference classes/functions.
 
     python tests/golden/make_golden.py            # all small fixtures (~1 min)
-    python tests/golden/make_golden.py --full     # also the B=64, L=512 record (~2 min)
+    python tests/golden/make_golden.py --full     # also the B=64, L=512 records g8 (~2 min) and g9 (~5 min)
 
 torch_geometric (an unrelated import of the reference's dataset module) is absent here, so an
 empty stand-in module is registered before the import; no reference code is changed.
@@ -226,7 +226,33 @@ def g6_adam(ref):
 
 
 class ListLoader(list):
-    pass
+    """A list that train_wgan can enumerate and len().  At B=64, L=512 one iteration's double-backward
+    graph takes ~30 GiB of host memory and the loop's local names (gp, d_loss, fake_data, ...) keep the
+    previous iteration's graph alive until they are rebound, i.e. while the next one is being built: two
+    generations do not fit in this container.  Before a batch is handed out, the harness therefore
+    unbinds those dead names in the caller's frame and runs the cycle collector.  No arithmetic of the
+    reference is touched: every one of these names is assigned again before it is read."""
+    DEAD = ("gp", "d_loss", "g_loss", "real_validity", "fake_validity", "fake_data", "out", "real_class_output",
+            "fake_class_output", "d_class_loss", "g_class_loss", "packed_input", "real_data")
+
+    def __iter__(self):
+        import ctypes
+        import gc
+        for k, item in enumerate(list.__iter__(self)):
+            f = sys._getframe(1)
+            while f is not None and f.f_code.co_name != "train_wgan":
+                f = f.f_back
+            if f is not None and k > 0:
+                for name in self.DEAD:
+                    if name in f.f_locals:
+                        f.f_locals[name] = None
+                ctypes.pythonapi.PyFrame_LocalsToFast(ctypes.py_object(f), ctypes.c_int(0))
+            gc.collect()
+            if os.environ.get("GOLDEN_TRACE"):
+                import resource
+                print(f"[batch {k}] peak RSS so far {resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2**20:.1f} GiB",
+                      file=sys.__stderr__, flush=True)
+            yield item
 
 
 def run_reference_steps(ref, pg, pd, batches, noises, vocab, gen_seq_len, opt_ns):
@@ -319,6 +345,45 @@ def g8_full_size(ref):
     save("g8_full_size.pt", out)
 
 
+def g9_full_step_full_size(ref):
+    """One FULL step and the start of the next at the north-star shape through the reference's own
+    train_wgan: 6 batches at B=64, L=512, V=175, generator seq_len 512, ADFA-shaped lengths that differ
+    from batch to batch (5 critic updates + the generator update after the first, then the 6th batch with
+    its critic and generator update; peaks at ~62 GiB of host memory).  Records the printed losses, every critic gradient of updates 0 and
+    5, the final critic parameters, and heads / update norms / BatchNorm buffers of the generator."""
+    import time
+    ns = argparse.Namespace(vocab_size=175, epochs=1, batch_size=64, lr=2e-4, b1=0.5, b2=0.999, latent_dim=100,
+                            seq_len=512, n_critic=5, clip_value=0.01, lambda_gp=10.0, hard=False, tau=0.5)
+    pg = common.generator_params(901, 175, 512)
+    pd = common.critic_params(902)
+    batches = [common.batch(910 + i, 64, 512, lengths=common.adfa_lengths(930 + i, 64).tolist()) for i in range(6)]
+    noises = [common.noise(920 + i, 64, 512) for i in range(6)]
+    t0 = time.time()
+    G, D, text, snaps = run_reference_steps(ref, pg, pd, batches, noises, 175, 512, ns)
+    out = {"seconds": torch.tensor(time.time() - t0),
+           "printed_losses": torch.tensor(parse_losses(text), dtype=torch.float64)}
+    for it in range(6):
+        for n, v in snaps["D"][it].items():
+            if it in (0, 5):
+                out[f"D.grad{it}.{n}"] = v
+            out[f"D.grad_norm{it}.{n}"] = v.double().norm()
+    for n, v in D.state_dict().items():
+        out[f"D.{n}"] = v.clone()
+    for n, v in G.state_dict().items():
+        if v.numel() > 200000:
+            out[f"G.delta_norm.{n}"] = (v - pg[n]).double().norm()
+            # the LAST rows (time step 511): the critic's gradient reaches the early time steps of a
+            # 512-step sequence vanishingly small, Adam leaves the first rows exactly where they were
+            out[f"G.tail.{n}"] = v.reshape(-1)[-65536:].clone()
+        elif "num_batches" not in n:
+            out[f"G.{n}"] = v.clone()
+    for it in range(2):
+        for n, v in snaps["G"][it].items():
+            out[f"G.grad_norm{it}.{n}"] = v.double().norm()
+    print("g9: reference seconds", float(out["seconds"]), out["printed_losses"])
+    save("g9_full_step_full_size.pt", out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
@@ -328,7 +393,7 @@ def main():
     ref = import_reference()
     todo = [g1_sampler, g2_generator, g3_critic, g4_gp, g5_ce, g6_adam, g7_full_step]
     if a.full:
-        todo.append(g8_full_size)
+        todo += [g8_full_size, g9_full_step_full_size]
     for fn in todo:
         if a.only and a.only not in fn.__name__:
             continue

@@ -342,3 +342,81 @@ def test_linear_small_batch_matches_torch(B, N, K):
     ops.linear_fwd_small_batch(x, W, b, y)
     torch.cuda.synchronize()
     assert rel(y, x.double() @ W.double().T + b.double()) < 1e-5
+
+
+def test_adam_matches_reference_golden(golden):
+    """s2g_adam against torch.optim.Adam(lr=2e-4, betas=(0.5, 0.999)) as recorded from the reference's
+    optimizer (g6): three consecutive steps, gradients spanning three decades; the tensor whose gradient
+    is None at step 1 is skipped by torch (no moment update, no step-count increment), which the host
+    mirrors by not launching for it and keeping a step count per tensor."""
+    from s2g import ops
+    G = golden("g6_adam.pt")
+    state = {}
+    for name, w0 in (("w", G["w0"]), ("w2", G["w20"])):
+        n = (w0.numel() + 3) // 4 * 4                  # 16-byte granularity of the kernel's accesses
+        buf = torch.zeros(4, n, device=DEV)             # p, g, m, v (16-byte aligned rows)
+        buf[0, :w0.numel()] = w0.reshape(-1).to(DEV)
+        state[name] = [buf, 0, w0.numel()]
+    for s in range(3):
+        for name, key in (("w", f"gw{s}"), ("w2", f"gw2{s}")):
+            buf, t, n = state[name]
+            if key not in G:
+                continue                                 # grad is None: torch skips the tensor
+            buf[1, :n] = G[key].reshape(-1).to(DEV)
+            state[name][1] = t = t + 1
+            ops.adam(buf[0], buf[1], buf[2], buf[3], 2e-4, 0.5, 0.999, 1e-8, t)
+        torch.cuda.synchronize()
+        for name, key in (("w", f"w{s + 1}"), ("w2", f"w2{s + 1}")):
+            buf, _, n = state[name]
+            want = G[key].reshape(-1)
+            got = buf[0, :n].cpu()
+            assert rel(got, want) < 1e-6, (name, s)
+            # the UPDATE itself (parameters hide a wrong step behind their norm): p_new - p_old
+            prev = G[key[:-1] + str(s)].reshape(-1)
+            if float((want - prev).abs().max()) > 0:
+                assert rel(got - prev, want - prev) < 1e-3, (name, s)
+
+
+def test_loss_kernels_match_reference_golden(golden):
+    """s2g_critic_loss / s2g_generator_loss / s2g_critic_head against CrossEntropyLoss(weight=[1,2]) applied
+    to softmax probabilities (the reference's double softmax, wgan_gp.py:268,299,310,338) as recorded in g5:
+    loss value and d loss / d logits."""
+    from s2g.lib import call
+    from s2g.ops import ptr, stream_ptr
+    G = golden("g5_ce.pt")
+    logits, labels = G["logits"], G["labels"]
+    B = labels.numel()
+    wsum = float(torch.tensor([1.0, 2.0])[labels].sum())
+    g = common.gen(71)
+    val = torch.randn(3 * B, generator=g)
+    out = torch.zeros(3 * B, 3)
+    out[:, 0] = val
+    out[:B, 1:] = logits
+    out[B:2 * B, 1:] = logits.flip(0)                  # a different set of logits for the fake third
+    lab = labels.to(DEV)
+    o = out.to(DEV)
+    dout = torch.full((3 * B, 3), float("nan"), device=DEV)
+    losses = torch.full((4,), float("nan"), device=DEV)
+    call("s2g_critic_loss", ptr(o), ptr(lab), B, 1.0 / B, 1.0 / wsum, 1.0, 2.0, ptr(dout), ptr(losses), stream_ptr())
+    torch.cuda.synchronize()
+    crit = torch.nn.CrossEntropyLoss(torch.tensor([1.0, 2.0]))
+    lg2 = logits.flip(0).clone().requires_grad_(True)
+    ce2 = crit(torch.softmax(lg2, -1), labels)
+    (dl2,) = torch.autograd.grad(ce2, lg2)
+    d = dout.cpu()
+    assert abs(float(losses[0]) + float(val[:B].mean())) < 1e-6
+    assert abs(float(losses[1]) - float(val[B:2 * B].mean())) < 1e-6
+    assert abs(float(losses[2]) - 0.5 * (float(G["loss"]) + float(ce2))) < 1e-6
+    assert rel(d[:B, 1:], 0.5 * G["dlogits"]) < 1e-5
+    assert rel(d[B:2 * B, 1:], 0.5 * dl2) < 1e-5
+    assert torch.all(d[:B, 0] == -1.0 / B) and torch.all(d[B:2 * B, 0] == 1.0 / B)
+    assert torch.equal(d[2 * B:], torch.tensor([[1.0, 0.0, 0.0]]).repeat(B, 1))
+    # generator pass: -mean(validity) + 0.5 * (0.5 * CE)   (wgan_gp.py:338-340)
+    og = out[:B].contiguous().to(DEV)
+    dg = torch.full((B, 3), float("nan"), device=DEV)
+    lg = torch.full((4,), float("nan"), device=DEV)
+    call("s2g_generator_loss", ptr(og), ptr(lab), B, 1.0 / B, 1.0 / wsum, 1.0, 2.0, ptr(dg), ptr(lg), stream_ptr())
+    torch.cuda.synchronize()
+    assert abs(float(lg[0]) + float(val[:B].mean())) < 1e-6
+    assert abs(float(lg[1]) - 0.25 * float(G["loss"])) < 1e-6
+    assert rel(dg.cpu()[:, 1:], 0.25 * G["dlogits"]) < 1e-5

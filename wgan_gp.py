@@ -226,7 +226,12 @@ def _export_adam(optimizer, module, flat_m, flat_v, step):
 
 def train_wgan(generator, discriminator, optimizer_G, optimizer_D, train_dataloader, val_loader, opt, device):
     """Reference :261-382.  Same loop, prints and checkpoints; each batch's critic update and the
-    generator update (when i % n_critic == 0) run as the fused HIP step."""
+    generator update (when i % n_critic == 0) run as the fused HIP step, scheduled like
+    WGANGPTrainer.full_step: the loader is read one batch ahead, so the next fake batch (or the generator
+    step's own forward) is computed beside the current batch's second-order sweeps.
+    opt.device_rng (flag --device_rng, default off): draw z / Gumbel uniforms / alpha on the device instead
+    of the CPU generator; faster (no 23 MB of CPU draws and copies per batch at L = 512), but a given seed
+    then no longer reproduces the reference's noise."""
     device = torch.device(device)
     if device.type != "cuda":
         raise S2GError("train_wgan needs an MI355X (device 'cuda'); there is no CPU path")
@@ -246,44 +251,88 @@ def train_wgan(generator, discriminator, optimizer_G, optimizer_D, train_dataloa
     from tqdm import tqdm
     from sklearn.metrics import f1_score
 
+    device_rng = bool(getattr(opt, "device_rng", False))
+    V, Lg = generator.vocab_size, generator.seq_len
+
+    def to_dev(t):
+        # page-locked staging + an asynchronous copy on the current (the trainer's) stream: the host does not
+        # wait for the step that is still running
+        return t.pin_memory().to(device, non_blocking=True)
+
+    def upload(batch):
+        """Range checks on the host, then the batch as the kernels take it (int32 tokens / lengths)."""
+        if batch is None:
+            return None
+        padded_sequences, labels, lengths = batch
+        s2g_data.check_batch(padded_sequences, labels, lengths, vocab=opt.vocab_size,
+                             n_classes=generator.n_classes, T=padded_sequences.shape[1])
+        return dict(tok=to_dev(padded_sequences.to(torch.int32).contiguous()), lab=to_dev(labels),
+                    ln=to_dev(lengths.to(torch.int32)), wsum=class_weight_sum(labels), B=padded_sequences.shape[0],
+                    T=padded_sequences.shape[1])
+
+    # The reference draws z / U / alpha / U2 on the CPU generator and copies them (:291, :58, :228, :330).
+    # These helpers make the same draws in the same order -- z_i, U_i, alpha_i, [U2_i], z_i+1, U_i+1, ... --
+    # only EARLIER than the reference needs them, so that the fake batch of step i+1 and the generator
+    # forward of a generator step can be computed beside step i's second-order sweeps.  With
+    # opt.device_rng they return nothing and the trainer draws on the device (another stream of numbers).
+    def draw_zu(b):
+        if device_rng or b is None:
+            return {}
+        return dict(z=to_dev(randn(b["B"], generator.latent_dim)), U=to_dev(torch.rand((b["B"], Lg, V))))
+
+    def draw_alpha(b):
+        return None if device_rng else to_dev(rand((b["B"], 1, 1))).view(-1)
+
+    def draw_u2(b):
+        return None if device_rng else to_dev(torch.rand((b["B"], Lg, V)))
+
     for epoch in range(1, opt.epochs + 1):
         generator.train()
         discriminator.train()
-        for i, (padded_sequences, labels, lengths) in enumerate(tqdm(train_dataloader)):
-            s2g_data.check_batch(padded_sequences, labels, lengths, vocab=opt.vocab_size,
-                                 n_classes=generator.n_classes, T=padded_sequences.shape[1])
-            wsum = class_weight_sum(labels)
-            tok = padded_sequences.to(torch.int32).to(device).contiguous()
-            lab = labels.to(device)
-            ln = lengths.to(torch.int32).to(device)
-            # the reference draws z / U / alpha on the CPU generator and copies them (:291, :58, :228)
-            z = randn(tok.shape[0], generator.latent_dim).to(device)
-            U = torch.rand((tok.shape[0], generator.seq_len, generator.vocab_size)).to(device)
-            alpha = rand((tok.shape[0], 1, 1)).to(device)
-            tr.critic_step(tok, lab, ln, wsum, z=z, U=U, alpha=alpha.view(-1))
-            if i % opt.n_critic == 0:
-                U2 = torch.rand((tok.shape[0], generator.seq_len, generator.vocab_size)).to(device)
-                tr.generator_step(U=U2)
-                print(
-                    "[Epoch %d/%d] [Batch %d/%d] [D loss: %f] [G loss: %f]"
-                    % (epoch, opt.epochs, i, len(train_dataloader), tr.d_loss().item(), tr.g_loss().item())
-                )
-                if epoch % 5 == 0:
-                    sync_counters()
-                    torch.save(generator.state_dict(), f"saved_models/wgan_generator_{epoch}.pth")
-                if epoch % 5 == 0:
-                    with torch.no_grad():
-                        discriminator.eval()
-                        f1_scores = []
-                        for _, (vp, vl, vlen) in enumerate(val_loader):
-                            real = torch.nn.functional.one_hot(vp, opt.vocab_size).float().to(device)
-                            out = discriminator(torch.nn.utils.rnn.pack_padded_sequence(
-                                real, vlen, batch_first=True, enforce_sorted=False), vlen)
-                            preds = torch.argmax(out[:, 1:], dim=1).detach().cpu().tolist()
-                            f1_scores.append(f1_score(preds, vl.cpu().tolist()))
-                        avg_f1_score = torch.mean(torch.tensor(f1_scores, dtype=torch.float32))
-                        print(f"f1 score: {avg_f1_score:.4f}")
-                        discriminator.train()
+        # host-to-device copies and the steps all go to the trainer's non-blocking stream (see WGANGPTrainer.stream)
+        with tr.stream():
+            n_batches = len(train_dataloader)
+            it = iter(tqdm(train_dataloader))
+            cur = upload(next(it, None))
+            zu = draw_zu(cur)
+            i = 0
+            while cur is not None:
+                nxt = upload(next(it, None))            # the loader is read one batch ahead
+                gen_now = i % opt.n_critic == 0
+                alpha = draw_alpha(cur)
+                U2 = draw_u2(cur) if gen_now else None
+                zu_next = draw_zu(nxt)
+                # the generator is unchanged between this batch and the next unless it is updated now: then the
+                # next batch's fake sequences can be made ahead (same batch size: they land in a buffer of this shape)
+                ahead = None
+                if nxt is not None and not gen_now and nxt["B"] == cur["B"]:
+                    ahead = dict(labels=nxt["lab"], T=nxt["T"], lengths=nxt["ln"], z=zu_next.get("z"), U=zu_next.get("U"))
+                tr.critic_step(cur["tok"], cur["lab"], cur["ln"], cur["wsum"], z=zu.get("z"), U=zu.get("U"), alpha=alpha,
+                               next_batch=ahead, gen_next=dict(U=U2) if gen_now else None)
+                if gen_now:
+                    tr.generator_step(U=U2)
+                    d_loss, g_loss = tr.losses().tolist()
+                    print(
+                        "[Epoch %d/%d] [Batch %d/%d] [D loss: %f] [G loss: %f]"
+                        % (epoch, opt.epochs, i, n_batches, d_loss, g_loss)
+                    )
+                    if epoch % 5 == 0:
+                        sync_counters()
+                        torch.save(generator.state_dict(), f"saved_models/wgan_generator_{epoch}.pth")
+                    if epoch % 5 == 0:
+                        with torch.no_grad():
+                            discriminator.eval()
+                            f1_scores = []
+                            for _, (vp, vl, vlen) in enumerate(val_loader):
+                                real = torch.nn.functional.one_hot(vp, opt.vocab_size).float().to(device)
+                                out = discriminator(torch.nn.utils.rnn.pack_padded_sequence(
+                                    real, vlen, batch_first=True, enforce_sorted=False), vlen)
+                                preds = torch.argmax(out[:, 1:], dim=1).detach().cpu().tolist()
+                                f1_scores.append(f1_score(preds, vl.cpu().tolist()))
+                            avg_f1_score = torch.mean(torch.tensor(f1_scores, dtype=torch.float32))
+                            print(f"f1 score: {avg_f1_score:.4f}")
+                            discriminator.train()
+                cur, zu, i = nxt, zu_next, i + 1
     sync_counters()
     _export_adam(optimizer_D, discriminator, tr.mD_named, tr.vD_named, tr.tD)
     _export_adam(optimizer_G, generator, tr.mG_named, tr.vG_named, tr.tG)
