@@ -87,6 +87,16 @@ int s2g_gemm_tall(const float* A, long lda, const float* B, long ldb, float* C, 
  * CU; more workgroups than that would run in two rounds), 0 = all CUs of the device. */
 int s2g_linear_small_batch(const float* W, const float* x, const float* bias, float* y, int n_out, int batch, int K,
                            int max_workgroups, void* stream);
+/* Generator output layer + Gumbel-softmax + argmax in one kernel: what generate_fake_data.py:64-66 computes
+ * as generator(noise, labels, tau, hard).argmax(-1) from the last hidden activations x [batch, K]
+ * (wgan_gp.py:159, 169-171): tokens[b][t] = argmax_v (x[b] . W[t V + v] + bias[t V + v] + gumbel(u[b][t][v])),
+ * int64 [batch, L]; the [batch, L, V] logits and samples are never written.  The argmax of the sample equals
+ * the argmax of the perturbed logits for every tau > 0 and for hard and soft sampling alike (first index
+ * on ties, as torch.argmax).  U [batch, L, V]: the uniforms of wgan_gp.py:58, or NULL: drawn in the kernel
+ * with the numbering of s2g_gumbel_softmax_fwd_rng (same seed / offset -> same tokens as that sampler's
+ * argmax).  batch <= 64, K % 128 == 0, K <= 512, V <= 384, W and x 16-byte aligned. */
+int s2g_generate_tokens(const float* W, const float* x, const float* bias, const float* U, long long* tokens, int L,
+                        int V, int batch, int K, unsigned long long seed, unsigned long long offset, void* stream);
 /* nprob problems in ONE launch.  table_dev / prefix_dev are DEVICE arrays: S2GGemm[nprob] (every
  * problem of the weight-gradient shape: A = [rows, M] with sam == 1, M % 4 == 0, M <= 208,
  * sak % 4 == 0 and a 16-byte aligned base, kchunk > 0 set by the caller, no bias / act /

@@ -930,6 +930,171 @@ extern "C" __global__ __launch_bounds__(64 * WS_WAVES) void s2g_k_linear_wstream
   }
 }
 
+// The same weight stream fused with sampling and decoding (generate_fake_data.py:60-66: generator forward,
+// Gumbel-softmax, argmax(-1)): tokens[m][t] = argmax_v (logits[m][t][v] + gumbel(u[m][t][v])) without ever
+// writing the [M, L, V] logits or samples.  Softmax and the division by tau are monotone, so the argmax of
+// the sample (soft or straight-through one-hot) is the argmax of the perturbed logits; the first index wins
+// a tie, as torch.argmax does.  A workgroup owns TS consecutive time steps: their ceil(V/16) * TS feature
+// tiles are dealt to its 8 waves; a wave reduces its 16 features per batch row in registers (4 in-lane
+// values, then the 4 lane groups), leaves (max, index) per batch row and tile in LDS, and after a barrier
+// one wave per time step combines the tiles.  The accumulation order is the plain kernel's, so the logits
+// are bit-identical to s2g_k_linear_wstream's.  Uniforms: U [M, L, V] if given, else Philox with the
+// in-kernel sampler's numbering (counter (m * L + t) * 64 + v / 4, word v % 4).
+#include "rng.hip"
+#define GT_MAXTILES 48
+__device__ __forceinline__ float gumbel_of(float u) {
+  const float uu = 1e-10f + (1.0f - 1e-10f) * u;
+  return -logf(-logf(uu + 1e-20f) + 1e-20f);
+}
+extern "C" __global__ __launch_bounds__(64 * WS_WAVES) void s2g_k_generate_tokens(
+    const float* __restrict__ W, const float* __restrict__ X, const float* __restrict__ bias,
+    const float* __restrict__ U, long long* __restrict__ tokens, int L, int V, int M, int K, int TS,
+    unsigned long long seed, unsigned long long offset) {
+  extern __shared__ __attribute__((aligned(16))) float Xs[];
+  float* pmax = Xs + (size_t)K * WS_LD;                    // [tiles of the group][64]
+  int* pidx = reinterpret_cast<int*>(pmax + GT_MAXTILES * 64);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int k4n = K >> 2, total4 = 64 * k4n;
+  for (int idx = tid; idx < total4; idx += 64 * WS_WAVES) {
+    const int mm = idx / k4n, kq = 4 * (idx - mm * k4n);
+    const bool live = mm < M;
+    const float4 v = gload4(X + (live ? (long)mm * K + kq : 0));
+    float* d = Xs + kq * WS_LD + mm;
+    d[0] = live ? v.x : 0.0f; d[WS_LD] = live ? v.y : 0.0f; d[2 * WS_LD] = live ? v.z : 0.0f; d[3 * WS_LD] = live ? v.w : 0.0f;
+  }
+  __syncthreads();
+  const int ngrp = K >> 5, tps = (V + 15) >> 4;            // feature tiles per time step
+  const int i = lane & 15, kk = lane >> 4;
+  const int boff = 8 * kk * WS_LD + i;
+  const long N = (long)L * V;
+  for (int t0 = blockIdx.x * TS; t0 < L; t0 += gridDim.x * TS) {
+    const int nts = min(TS, L - t0);
+    for (int q = wave; q < tps * nts; q += WS_WAVES) {
+      const int ts = q / tps, tile = q - ts * tps, t = t0 + ts;
+      const long n0 = (long)t * V + 16 * tile;
+      const float* wp = W + min(n0 + i, N - 1) * K + 8 * kk;        // rows past the last feature: clamped, masked below
+      float4 ring[WS_PF][2];
+#pragma unroll
+      for (int e = 0; e < WS_PF; ++e) {
+        ring[e][0] = gload4(wp + 32 * e);
+        ring[e][1] = gload4(wp + 32 * e + 4);
+      }
+      f32x4 acc[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+      float bq[2][16];
+      auto bfrag = [&](int g, int h, float (&b)[16]) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) b[4 * c + j] = Xs[boff + (32 * g + 4 * h + c) * WS_LD + 16 * j];
+      };
+      bfrag(0, 0, bq[0]);
+      for (int g0 = 0; g0 < ngrp; g0 += WS_PF) {
+#pragma unroll
+        for (int e = 0; e < WS_PF; ++e) {
+          const int g = g0 + e;
+          const float4 w0 = ring[e][0], w1 = ring[e][1];
+          const int gn = g + WS_PF < ngrp ? g + WS_PF : 0;
+          ring[e][0] = gload4(wp + 32 * gn);
+          ring[e][1] = gload4(wp + 32 * gn + 4);
+          bfrag(g, 1, bq[1]);
+          __builtin_amdgcn_sched_barrier(0);
+          const float wa[4] = {w0.x, w0.y, w0.z, w0.w};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c], bq[0][4 * c + j], acc[j], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          bfrag(g + 1 < ngrp ? g + 1 : 0, 0, bq[0]);
+          __builtin_amdgcn_sched_barrier(0);
+          const float wb[4] = {w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[c], bq[1][4 * c + j], acc[j], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      // D[4 kk + r][i]: column v = 16 tile + 4 kk + r of time step t, batch row 16 j + i
+      const int v0 = 16 * tile + 4 * kk;
+      float bv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[r] = (bias && v0 + r < V) ? bias[(long)t * V + v0 + r] : 0.0f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int m = 16 * j + i;
+        const long row = (long)min(m, M - 1) * L + t;
+        float u[4];
+        if (U) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) u[r] = (v0 + r < V) ? U[row * V + v0 + r] : 0.5f;
+        } else {
+          const Philox4 ph = philox4x32_10((unsigned long long)row * 64 + (v0 >> 2), offset, seed);
+          u[0] = u01(ph.x); u[1] = u01(ph.y); u[2] = u01(ph.z); u[3] = u01(ph.w);
+        }
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float z = (acc[j][r] + bv[r]) + gumbel_of(u[r]);
+          if (v0 + r < V && z > best) { best = z; bi = v0 + r; }
+        }
+        // the four lane groups kk hold the other 12 columns of this tile for the same batch row
+#pragma unroll
+        for (int o = 16; o < 64; o <<= 1) {
+          const float ob = __shfl_xor(best, o);
+          const int oi = __shfl_xor(bi, o);
+          if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (kk == 0) { pmax[q * 64 + m] = best; pidx[q * 64 + m] = bi; }
+      }
+    }
+    __syncthreads();
+    if (wave < nts && lane < M) {
+      float best = -INFINITY;
+      int bi = 0x7fffffff;
+      for (int tile = 0; tile < tps; ++tile) {            // ascending columns: a later tile wins only if larger
+        const float ob = pmax[(wave * tps + tile) * 64 + lane];
+        const int oi = pidx[(wave * tps + tile) * 64 + lane];
+        if (ob > best) { best = ob; bi = oi; }
+      }
+      tokens[(long)lane * L + t0 + wave] = bi;
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int s2g_launch_generate_tokens(const float* W, const float* X, const float* bias, const float* U,
+                                          long long* tokens, int L, int V, int M, int K, unsigned long long seed,
+                                          unsigned long long offset, hipStream_t stream) {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -2;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&s2g_k_generate_tokens),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2;
+    cus = prop.multiProcessorCount;
+  }
+  const int tps = (V + 15) >> 4;
+  // time steps per workgroup: as many as fill the 8 waves evenly and still give every CU a group
+  int TS = 1;
+  while (TS < 8 && tps * (TS + 1) <= GT_MAXTILES && (L + TS) / (TS + 1) >= cus) ++TS;
+  if (TS == 1 && tps * 2 <= GT_MAXTILES && L >= 2) TS = 2;      // 11 tiles on 8 waves: two steps share the rounds
+  const size_t lds = ((size_t)K * WS_LD + 2 * GT_MAXTILES * 64) * sizeof(float);
+  int blocks = (L + TS - 1) / TS;
+  if (blocks > cus) blocks = cus;
+  hipLaunchKernelGGL(s2g_k_generate_tokens, dim3(blocks), dim3(64 * WS_WAVES), lds, stream, W, X, bias, U, tokens, L,
+                     V, M, K, TS, seed, offset);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 // max_workgroups: CUs the stream can reach (a CU-masked stream: fewer than the device has; a workgroup takes
 // a whole CU, so a grid larger than that would run in two rounds); 0 = all of the device's.
 extern "C" int s2g_launch_linear_wstream(const float* W, const float* X, const float* bias, float* Y, int N, int M,

@@ -99,6 +99,14 @@ int s2g_linear_small_batch(const float* W, const float* x, const float* bias, fl
   return s2g_launch_linear_wstream(W, x, bias, y, n_out, batch, K, max_workgroups, ST(stream));
 }
 
+int s2g_generate_tokens(const float* W, const float* x, const float* bias, const float* U, long long* tokens, int L,
+                        int V, int batch, int K, unsigned long long seed, unsigned long long offset, void* stream) {
+  if (!W || !x || !tokens || L <= 0 || V <= 0 || batch <= 0 || batch > 64 || K <= 0) return -1;
+  if ((K & 127) || K > 512 || ((V + 15) >> 4) > GT_MAXTILES / 2) return -1;
+  if ((((uintptr_t)W) | ((uintptr_t)x)) & 15) return -1;
+  return s2g_launch_generate_tokens(W, x, bias, U, tokens, L, V, batch, K, seed, offset, ST(stream));
+}
+
 int s2g_gemm_grouped(const GemmArgs* table_dev, const int* prefix_dev, int nprob, int total_blocks, int nz,
                      void* stream) {
   if (!table_dev || !prefix_dev || nprob <= 0 || nprob > 64 || total_blocks <= 0 || nz < 0) return -1;

@@ -126,6 +126,54 @@ class GeneratorEngine:
                               inv3=inv3, y_soft=y_soft, scale=(1.0 if mode == 2 else 1.0 / tau), B=B)
         return y
 
+    def hidden(self, z: torch.Tensor, labels: torch.Tensor, training: bool) -> torch.Tensor:
+        """The activations in front of the output Linear (wgan_gp.py:166-167, model[0..7]); with `training`
+        the BatchNorm layers use (and update) batch statistics, as Generator.forward in train mode."""
+        B = z.shape[0]
+        p, dev = self.params.views, self.device
+        x0 = torch.empty(B, LATENT, device=dev)
+        call("s2g_embed_mul", ptr(z), ptr(labels), ptr(p["label_embedding.weight"]), ptr(x0), B, LATENT,
+             self.n_classes, stream_ptr())
+        a1 = torch.empty(B, 128, device=dev)
+        ops.linear_fwd(x0, p["model.0.weight"], p["model.0.bias"], a1, act=1)
+        pre2 = torch.empty(B, 256, device=dev)
+        ops.linear_fwd(a1, p["model.2.weight"], p["model.2.bias"], pre2)
+        a2, _, _ = self._bn(pre2, "model.3", training, True, B, 256)
+        pre3 = torch.empty(B, 512, device=dev)
+        ops.linear_fwd(a2, p["model.5.weight"], p["model.5.bias"], pre3)
+        a3, _, _ = self._bn(pre3, "model.6", training, True, B, 512)
+        if training:
+            self.num_batches_tracked += 1
+        return a3
+
+    def generate_tokens(self, z: torch.Tensor, labels: torch.Tensor, U: Optional[torch.Tensor] = None,
+                        training: bool = False) -> torch.Tensor:
+        """generator(noise, labels, tau, hard).argmax(-1) of generate_fake_data.py:64-66 as int64 [B, L], with
+        the output layer, the Gumbel perturbation and the argmax in one kernel (no [B, L, V] tensor exists).
+        Equal to the argmax of forward()'s sample for every tau and for hard and soft sampling.
+        U [B, L, V]: injected uniforms; None: drawn in the kernel."""
+        ops._chk(z, name="noise")
+        ops._chk(labels, torch.int64, "labels")
+        B = z.shape[0]
+        if z.shape[1] != LATENT or labels.shape[0] != B:
+            raise S2GError("generator: noise must be [B,100] and labels [B]")
+        if U is not None:
+            ops._chk(U, name="U")
+            if tuple(U.shape) != (B, self.L, self.V):
+                raise S2GError("generate_tokens: U must be [B, seq_len, vocab]")
+        p = self.params.views
+        tokens = torch.empty(B, self.L, dtype=torch.int64, device=self.device)
+        if training:
+            a3 = self.hidden(z, labels, True)          # batch statistics couple the samples: one pass
+        for lo in range(0, B, 64):                     # the kernel takes up to 64 samples per launch
+            hi = min(B, lo + 64)
+            a = a3[lo:hi] if training else self.hidden(z[lo:hi].contiguous(), labels[lo:hi].contiguous(), False)
+            seed, off = (0, 0) if U is not None else self.rng.take()
+            call("s2g_generate_tokens", ptr(p["model.8.weight"]), ptr(a.contiguous()), ptr(p["model.8.bias"]),
+                 ptr(U[lo:hi].contiguous()) if U is not None else None, ptr(tokens, lo * self.L), self.L, self.V,
+                 hi - lo, 512, seed, off, stream_ptr())
+        return tokens
+
     # ------------------------------------------------------------------ backward
     def _bn_bwd(self, a, da, xhat, inv, name, B, F_):
         g = self.grads.views

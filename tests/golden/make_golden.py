@@ -384,6 +384,70 @@ def g9_full_step_full_size(ref):
     save("g9_full_step_full_size.pt", out)
 
 
+def g10_generate_fake_data(ref):
+    """The consumer of the training step's output, generate_fake_data.py:24-30, 60-66, 74-79: a checkpoint
+    written as torch.save(generator.state_dict(), ...) (wgan_gp.py:350-352) is loaded by the reference's
+    own load_model into the reference's Generator(vocab_size=175) (seq_len 120), put in eval mode and
+    sampled as generator(noise, labels, tau, hard).argmax(-1).tolist().  Records the token lists for hard
+    False / True and two temperatures.  fetch_graphs itself needs torch_geometric (absent here); what IS
+    recorded of it is the vocabulary quirk its first statement has (graph_encoder.py:30-37, 64): the
+    generated tokens are ints while the loaded vocabulary's keys are strings, so build_vocabulary mints a
+    new id (>= 175) for every distinct generated token instead of finding it."""
+    import tempfile
+    # seaborn (a plotting import of the reference's utils.py, pulled in through wgan.py) is absent here: an
+    # empty stand-in module, like torch_geometric's; no reference code is changed
+    sys.modules.setdefault("seaborn", types.ModuleType("seaborn"))
+    import generate_fake_data as gfd            # the reference's script (imports wgan / graph_encoder as well)
+    pg = common.generator_params(1101, 175, 120)
+    sd = dict(pg)
+    bn = common.bn_buffers()
+    g = common.gen(1102)
+    # running statistics as a trained checkpoint has them (not the initial 0 / 1)
+    bn["model.3.running_mean"] = torch.randn(256, generator=g) * 0.05
+    bn["model.3.running_var"] = 1.0 + 0.2 * torch.rand(256, generator=g)
+    bn["model.6.running_mean"] = torch.randn(512, generator=g) * 0.05
+    bn["model.6.running_var"] = 1.0 + 0.2 * torch.rand(512, generator=g)
+    bn["model.3.num_batches_tracked"] = torch.tensor(37)
+    bn["model.6.num_batches_tracked"] = torch.tensor(37)
+    sd.update(bn)
+    n = 70                                        # more than one 64-sample launch of the fused kernel
+    noise = torch.randn((n, 100), generator=g)
+    labels = torch.zeros((n,), dtype=torch.long)  # generate_fake_data.py:115: class 0 = malware
+    out = {"noise": noise, "labels": labels}
+    for k, v in bn.items():
+        out[f"bn.{k}"] = v
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.makedirs(os.path.join(tmp, "saved_models"))
+        torch.save(sd, os.path.join(tmp, "saved_models", "wgan_generator_5.pth"))
+        os.chdir(tmp)
+        try:
+            args = argparse.Namespace(vocab_size=175, num_classes=2, num_layers=3, softmax="gumbel_softmax")
+            model = gfd.load_model("wgan_generator_5.pth", args)
+        finally:
+            os.chdir(cwd)
+    model.eval()
+    for tau in (0.5, 1.0):
+        for hard in (False, True):
+            U = torch.rand((n, 120, 175), generator=common.gen(1103 + int(hard) + int(tau * 10)))
+            q = Queue(); q.push(U)
+            with injected(ref, q, Queue(), Queue()), torch.no_grad():
+                gen_data = model(noise, labels, tau, hard).argmax(-1)
+            out[f"U.tau{tau}.hard{int(hard)}.seed"] = torch.tensor(1103 + int(hard) + int(tau * 10))
+            out[f"tokens.tau{tau}.hard{int(hard)}"] = gen_data
+    # the vocabulary quirk (recorded, not fixed)
+    enc = gfd.GraphEncoder()
+    enc.syscall_vocabs = {str(i): i for i in range(175)}        # what load_vocabulary returns: string keys
+    seq = out["tokens.tau0.5.hard1"][0].tolist()
+    enc.build_vocabulary(seq)
+    minted = sorted(v for k, v in enc.syscall_vocabs.items() if isinstance(k, int))
+    out["quirk.sequence0_distinct_tokens"] = torch.tensor(len(set(seq)))
+    out["quirk.minted_ids"] = torch.tensor(minted)
+    print("g10: distinct tokens in sequence 0:", len(set(seq)), "-> ids minted by build_vocabulary:",
+          minted[:3], "...", minted[-1])
+    save("g10_generate_fake_data.pt", out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
@@ -391,7 +455,7 @@ def main():
     a = ap.parse_args()
     torch.manual_seed(0)
     ref = import_reference()
-    todo = [g1_sampler, g2_generator, g3_critic, g4_gp, g5_ce, g6_adam, g7_full_step]
+    todo = [g1_sampler, g2_generator, g3_critic, g4_gp, g5_ce, g6_adam, g7_full_step, g10_generate_fake_data]
     if a.full:
         todo += [g8_full_size, g9_full_step_full_size]
     for fn in todo:

@@ -129,6 +129,31 @@ class Generator(nn.Module):
         return y
 
 
+def _generator_sample_tokens(self, noise, labels, uniforms=None):
+    """tokens = self(noise, labels, tau, hard).argmax(-1) (generate_fake_data.py:64-66) as int64 [B, seq_len],
+    computed by one fused kernel (output layer + Gumbel perturbation + argmax); the result does not depend
+    on tau or hard.  uniforms: optional [B, seq_len, vocab] draws; default: torch.rand on the CPU generator,
+    as the reference's sampler draws them (:58)."""
+    if not noise.is_cuda:
+        raise S2GError("Generator.sample_tokens needs GPU tensors (MI355X-only implementation, no CPU path)")
+    s2g_data.check_batch(labels=labels, n_classes=self.n_classes)
+    eng = self.engine(noise.device)
+    if uniforms is None and self.gumbel_softmax.act == "gumbel_softmax":
+        uniforms = torch.rand((noise.shape[0], self.seq_len, self.vocab_size)).to(noise.device)
+    if self.gumbel_softmax.act != "gumbel_softmax":
+        raise S2GError("Generator.sample_tokens: only the Gumbel-softmax sampler is fused")
+    with torch.no_grad():
+        tok = eng.generate_tokens(noise.contiguous().float(), labels.contiguous(), uniforms.contiguous().float(),
+                                  training=self.training)
+    if self.training:
+        for m in (self.model[3], self.model[6]):
+            m.num_batches_tracked += 1
+    return tok
+
+
+Generator.sample_tokens = _generator_sample_tokens
+
+
 class Discriminator(nn.Module):
     """Reference :175-223: nn.LSTM(input, hidden=50, layers=2, dropout) -> last layer's final hidden
     state -> Linear(50, num_classes + 1).  Accepts a PackedSequence or a dense [B,T,V] tensor."""
