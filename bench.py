@@ -121,6 +121,9 @@ def main():
     ap.add_argument("--lengths", default="fixed", choices=["fixed", "adfa"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--drop-rate", type=float, default=0.3)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="f32 (default, the headline): exact-fp32 MFMA everywhere; bf16: bf16 operands / fp32 accumulation "
+                         "in the critic's input-layer products (the 2e-2 path)")
     ap.add_argument("--path", default="trainer", choices=["trainer", "train_wgan"],
                     help="which path `value` is measured on: WGANGPTrainer.full_step on device-resident batches "
                          "(default, the headline) or the drop-in train_wgan() loop of wgan_gp.py on a CPU loader; "
@@ -158,7 +161,8 @@ def main():
 
     import common
     tr = WGANGPTrainer(V, GEN_SEQ_LEN, dev, lr=2e-4, b1=0.5, b2=0.999, lambda_gp=10.0, tau=0.5, hard=False,
-                       n_critic=N_CRITIC, drop_rate=a.drop_rate, comm=comm, seed=42 + rank)   # per-rank noise streams
+                       n_critic=N_CRITIC, drop_rate=a.drop_rate, comm=comm, seed=42 + rank,   # per-rank noise streams
+                       dtype=a.dtype)
     if os.environ.get("S2G_NO_OVERLAP") == "1":
         tr.D.overlap = False                                      # one stream, launch after launch (debugging aid)
     tr.G.load(common.generator_params(801, V, GEN_SEQ_LEN))      # same initial weights on every rank
@@ -258,7 +262,9 @@ def main():
         line = {
             "metric": "WGAN-GP train sequences/sec at V=175 L=512", "value": seqs / dt, "unit": "sequences/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if a.dtype == "f32" else "bf16 operands / f32 accumulate in the input-layer products, f32 elsewhere",
+            "data": "synthetic",
             "config": {"workload": "full WGAN-GP step = 5 critic updates (real+fake+gradient penalty) + 1 generator "
                                    "update; V=175, L=512, B=64 per GPU, generator seq_len 512, tau 0.5, lambda_gp 10, "
                                    f"critic dropout {a.drop_rate}, lengths {a.lengths}",

@@ -80,6 +80,11 @@ int s2g_gemm_f32(const S2GGemm* args, int nsplit, void* stream);
  * column roundup(N, 4).  A and B are each read once per 64-row block. */
 int s2g_gemm_tall(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N, int K,
                   void* stream);
+/* the same products with both operands rounded to bf16 and fp32 accumulation (v_mfma_f32_16x16x32_bf16):
+ * the optional reduced-precision path of the step (results within 2e-2 relative of the fp32 reference);
+ * N <= 224, K <= 224, any lda / ldb / alignment. */
+int s2g_gemm_tall_bf16(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N, int K,
+                       void* stream);
 /* nn.Linear forward for a small batch and many output features (the generator's 512 -> L*V output layer,
  * wgan_gp.py:159): y[batch, n_out] = x[batch, K] W[n_out, K]^T + bias; batch <= 64, n_out % 16 == 0,
  * K % 128 == 0, K <= 512, W / y / bias 16-byte aligned.  W is streamed from HBM exactly once.

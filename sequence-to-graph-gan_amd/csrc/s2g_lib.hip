@@ -4,6 +4,7 @@
 #include "lstm_fwd.hip"
 #include "lstm_bwd.hip"
 #include "gemm.hip"
+#include "gemm_bf16.hip"
 #include "sampler.hip"
 #include "elementwise.hip"
 #include <math.h>
@@ -88,6 +89,13 @@ int s2g_gemm_tall(const float* A, long lda, const float* B, long ldb, float* C, 
   if (!A || !B || !C || M <= 0 || K <= 0 || N <= 160 || N > 224) return -1;
   if ((ldb & 3) || ldb < ((N + 3) & ~3) || (((uintptr_t)B) & 15) || lda < K || ldc < N) return -1;
   return s2g_launch_gemm_tall(A, lda, B, ldb, C, ldc, M, N, K, ST(stream));
+}
+
+int s2g_gemm_tall_bf16(const float* A, long lda, const float* B, long ldb, float* C, long ldc, int M, int N, int K,
+                       void* stream) {
+  if (!A || !B || !C || M <= 0 || K <= 0 || K > TB_KMAX || N <= 0 || N > 224) return -1;
+  if (lda < K || ldb < N || ldc < N) return -1;
+  return s2g_launch_gemm_tall_bf16(A, lda, B, ldb, C, ldc, M, N, K, ST(stream));
 }
 
 int s2g_linear_small_batch(const float* W, const float* x, const float* bias, float* y, int n_out, int batch, int K,

@@ -75,6 +75,7 @@ class CriticEngine:
         self.overlap = True           # run the work that does not depend on sweeps C/D beside them (critic_iteration)
         self._side = None             # (stream, fork event, join event, scratch) of that second stream
         self.stream_g = None          # CU-masked stream of the prefetch hook (created with _side)
+        self.bf16 = False             # tall products of the input layer on bf16 MFMA (2e-2 path); default exact fp32
         self.reserve_comm_stream = False   # data-parallel runs: the collective library owns a stream (and a hardware
                                            # queue) of its own, so the prefetch hook shares the second stream instead
         self._m2_events = None        # (weights packed, M2 built) when M2 is built on a side stream
@@ -224,7 +225,7 @@ class CriticEngine:
     def project(self, x: torch.Tensor, out: torch.Tensor) -> None:
         """out[rows,200] = x[rows,V] @ W_ih0^T (internal gate order, no bias)."""
         rows = x.numel() // self.V
-        ops.gemm_tall(ptr(x), self.V, ptr(self.WT0), G4, ptr(out), G4, rows, G4, self.V)
+        ops.gemm_tall(ptr(x), self.V, ptr(self.WT0), G4, ptr(out), G4, rows, G4, self.V, bf16=self.bf16)
 
     def side(self):
         """The second HIP stream of critic_iteration, confined to 3/4 of the CUs: sweeps C and D run
@@ -576,7 +577,8 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
     # 175-wide direction v = coef_b * g itself feeds one weight-gradient product only and is built
     # beside sweep C (first_order below).
     r_int = 2 * B * Tw
-    ops.gemm_tall(ptr(ws["delta0"], r_int * G4), G4, ptr(eng.m2()), G4, ptr(ws["Pv"]), G4, B * Tw, G4, G4)
+    ops.gemm_tall(ptr(ws["delta0"], r_int * G4), G4, ptr(eng.m2()), G4, ptr(ws["Pv"]), G4, B * Tw, G4, G4,
+                  bf16=eng.bf16)
     # only the reduction stays on the critical path: sweep C scales its own seed by coef_b, and the
     # penalty values / norms come out beside it (first_order)
     def gp_dots():
@@ -619,7 +621,8 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         # g = delta0 W_ih0, the 175-wide input gradient itself: penalty values and norms (wgan_gp.py:255-256)
         # and, scaled in place, v = coef_b * g: the direction of the penalty's second-order term in input
         # space.  Nothing here waits for the reduction the caller's stream does for sweep C.
-        ops.gemm_tall(ptr(ws["delta0"], r_int * G4), G4, ptr(eng.W0p), eng.Vp, ptr(ws["G"]), V, B * Tw, V, G4)
+        ops.gemm_tall(ptr(ws["delta0"], r_int * G4), G4, ptr(eng.W0p), eng.Vp, ptr(ws["G"]), V, B * Tw, V, G4,
+                      bf16=eng.bf16)
         call("s2g_gp_norm_penalty", ptr(ws["G"]), B, Tw * V, float(lambda_gp), float(n_global), ptr(ws["pen"]),
              ptr(ws["norms"]), 1, s_)
         call("s2g_one_hot", ptr(tokens), ptr(lengths), T, ptr(ws["xreal"]), B * T, V, s_)
@@ -774,7 +777,7 @@ def critic_forward_backward_fake(eng: CriticEngine, fake: torch.Tensor, labels: 
             loss_values()
             vals_done.record()
     eng.sweep_bwd(ws, ptr(desc), B, Tf, mask, head=head)
-    ops.gemm_tall(ptr(ws["delta0"]), G4, ptr(eng.W0p), eng.Vp, ptr(ws["dfake"]), V, B * Tf, V, G4)
+    ops.gemm_tall(ptr(ws["delta0"]), G4, ptr(eng.W0p), eng.Vp, ptr(ws["dfake"]), V, B * Tf, V, G4, bf16=eng.bf16)
     if side is not None:
         torch.cuda.current_stream().wait_event(vals_done)
     else:

@@ -56,6 +56,7 @@ SIGNATURES = {
     "s2g_argmax_rows": [P, P, L, I, P],
     "s2g_gemm_f32": [ctypes.POINTER(S2GGemm), I, P],
     "s2g_gemm_tall": [P, L, P, L, P, L, I, I, I, P],
+    "s2g_gemm_tall_bf16": [P, L, P, L, P, L, I, I, I, P],
     "s2g_gemm_grouped": [P, P, I, I, I, P],
     "s2g_generate_tokens": [P, P, P, P, P, I, I, I, I, U64, U64, P],
     "s2g_linear_small_batch": [P, P, P, P, I, I, I, I, P],

@@ -48,10 +48,14 @@ def gemm_raw(A: int, sam: int, sak: int, B: int, sbk: int, sbn: int, C: int, ldc
     call("s2g_gemm_f32", ctypes.byref(g), nsplit, stream_ptr())
 
 
-def gemm_tall(A: int, lda: int, B: int, ldb: int, C: int, ldc: int, M: int, N: int, K: int) -> None:
+def gemm_tall(A: int, lda: int, B: int, ldb: int, C: int, ldc: int, M: int, N: int, K: int,
+              bf16: bool = False) -> None:
     """C[M,N] = A[M,K] B[K,N], row-major: the tall products of the critic's input layer.  Shapes the
-    tall kernel does not cover (N outside (160, 224], B rows not 16-byte) go to the generic kernel."""
-    if 160 < N <= 224 and ldb % 4 == 0 and B % 16 == 0:
+    tall kernel does not cover (N outside (160, 224], B rows not 16-byte) go to the generic kernel.
+    bf16: operands rounded to bf16, fp32 accumulation (the reduced-precision path; K, N <= 224)."""
+    if bf16 and N <= 224 and K <= 224:
+        call("s2g_gemm_tall_bf16", A, lda, B, ldb, C, ldc, M, N, K, stream_ptr())
+    elif 160 < N <= 224 and ldb % 4 == 0 and B % 16 == 0:
         call("s2g_gemm_tall", A, lda, B, ldb, C, ldc, M, N, K, stream_ptr())
     else:
         gemm_raw(A, lda, 1, B, ldb, 1, C, ldc, M, N, K)

@@ -37,7 +37,7 @@ class WGANGPTrainer:
     def __init__(self, vocab: int, gen_seq_len: int, device, lr: float = 2e-4, b1: float = 0.5, b2: float = 0.999,
                  lambda_gp: float = 10.0, tau: float = 0.5, hard: bool = False, n_critic: int = 5,
                  drop_rate: float = 0.3, comm=None, gen_engine=None, critic_engine=None, eps: float = 1e-8,
-                 adam_g=None, seed: Optional[int] = None):
+                 adam_g=None, seed: Optional[int] = None, dtype: str = "f32"):
         """lr, b1, b2, eps: Adam hyper-parameters of the critic's optimizer (wgan_gp.py:406) and, unless
         adam_g = (lr, b1, b2, eps) says otherwise, of the generator's (wgan_gp.py:405).
         seed: seed of the device-side draws (z, Gumbel uniforms, alpha, dropout masks) that are not injected."""
@@ -47,6 +47,10 @@ class WGANGPTrainer:
         self.G.comm = self.comm
         self.D = critic_engine or CriticEngine(vocab, self.device)
         self.D.reserve_comm_stream = self.comm.world > 1
+        if dtype not in ("f32", "bf16"):
+            raise S2GError("dtype must be 'f32' (exact fp32 MFMA everywhere) or 'bf16' (bf16 operands in the critic's "
+                           "input-layer products, fp32 accumulation and fp32 recurrence)")
+        self.D.bf16 = dtype == "bf16"
         self.D.repack()
         self.lr, self.b1, self.b2, self.eps = lr, b1, b2, eps
         self.adam_g = tuple(adam_g) if adam_g is not None else (lr, b1, b2, eps)

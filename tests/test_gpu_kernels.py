@@ -420,3 +420,39 @@ def test_loss_kernels_match_reference_golden(golden):
     assert abs(float(lg[0]) + float(val[:B].mean())) < 1e-6
     assert abs(float(lg[1]) - 0.25 * float(G["loss"])) < 1e-6
     assert rel(dg.cpu()[:, 1:], 0.25 * G["dlogits"]) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(32768, 200, 175), (32768, 200, 200), (4096, 175, 200), (130, 175, 200), (5, 33, 7)])
+def test_gemm_tall_bf16_matches_bf16_rounded_reference(M, N, K):
+    """s2g_gemm_tall_bf16 = (A rounded to bf16) @ (B rounded to bf16) accumulated in fp32: against a float64
+    product of the ROUNDED operands it must be fp32-accurate (the rounding is the only approximation), and
+    against the unrounded product within the 2e-2 the reduced-precision path is entitled to."""
+    from s2g import ops
+    from s2g.ops import ptr
+    g = common.gen(91)
+    A = torch.randn(M, K, generator=g).to(DEV)
+    B = (torch.randn(K, N, generator=g) * 0.1).to(DEV)
+    C = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm_tall(ptr(A), K, ptr(B), N, ptr(C), N, M, N, K, bf16=True)
+    torch.cuda.synchronize()
+    Ar, Br = A.bfloat16().double(), B.bfloat16().double()
+    assert rel(C, Ar @ Br) < 1e-5
+    assert rel(C, A.double() @ B.double()) < 2e-2
+
+
+def test_gemm_tall_bf16_strided_operands():
+    """padded leading dimensions, as the critic uses them (W0p rows are padded to 176 floats)"""
+    from s2g import ops
+    from s2g.ops import ptr
+    g = common.gen(92)
+    M, N, K = 1000, 175, 200
+    A = torch.randn(M, 208, generator=g).to(DEV)
+    B = torch.zeros(K, 176)
+    B[:, :N] = torch.randn(K, N, generator=g) * 0.1
+    B = B.to(DEV)
+    C = torch.full((M, 180), float("nan"), device=DEV)
+    ops.gemm_tall(ptr(A), 208, ptr(B), 176, ptr(C), 180, M, N, K, bf16=True)
+    torch.cuda.synchronize()
+    want = A[:, :K].bfloat16().double() @ B[:, :N].bfloat16().double()
+    assert rel(C[:, :N], want) < 1e-5
+    assert torch.isnan(C[:, N:]).all()          # nothing written outside the N columns

@@ -217,6 +217,42 @@ def test_full_step_at_full_size_matches_reference_golden(golden):
         assert_close(tr.G.buffers[b].cpu(), G[f"G.{b}"], TOL, b)
 
 
+@pytest.mark.parametrize("tag", ["fixed", "adfa"])
+def test_bf16_path_at_full_size_within_2e_2(golden, tag):
+    """The reduced-precision path (dtype="bf16": bf16 operands in the critic's input-layer products, fp32
+    accumulation, fp32 recurrence) at the north-star shape against the reference's fp32 gradients (g8):
+    2e-2 relative, the bound the north star states for bf16."""
+    from s2g.trainer import WGANGPTrainer
+    G = golden("g8_full_size.pt")
+    lengths = [512] * 64 if tag == "fixed" else common.adfa_lengths(805, 64).tolist()
+    tr = WGANGPTrainer(175, 512, DEV, drop_rate=0.0, dtype="bf16")
+    tr.G.load(common.generator_params(801, 175, 512)); tr.D.load(common.critic_params(802))
+    tok, lab, ln, wsum = dev_batch(*common.batch(810, 64, 512, lengths=lengths))
+    nz = {n: v.to(DEV) for n, v in common.noise(820, 64, 512).items()}
+    tr.critic_step(tok, lab, ln, wsum, nz["z"], nz["U"], nz["alpha"].view(-1).contiguous())
+    d_loss = float(tr.d_loss())
+    dgr = {n: v.cpu().clone() for n, v in tr.D.grads.views.items()}
+    tr.generator_step(U=nz["U2"])
+    g_loss = float(tr.g_loss())
+    torch.cuda.synchronize()
+    printed = G[f"{tag}.printed_losses"]
+    BF = 2e-2
+    assert abs(d_loss - float(printed[0, 0])) < BF * abs(d_loss)
+    assert abs(g_loss - float(printed[0, 1])) < BF * max(1.0, abs(g_loss))
+    worst = 0.0
+    for n, v in dgr.items():
+        assert_close(v, G[f"{tag}.D.grad.{n}"], BF, f"D grad {n}", atol=1e-7)
+        worst = max(worst, float((v.double() - G[f"{tag}.D.grad.{n}"].double()).norm() / G[f"{tag}.D.grad.{n}"].double().norm()))
+    for n, v in tr.G.grads.views.items():
+        if n in NOISE_ONLY:
+            continue
+        if f"{tag}.G.grad.{n}" in G:
+            assert_close(v.cpu(), G[f"{tag}.G.grad.{n}"], BF, f"G grad {n}", atol=1e-7)
+        else:
+            assert_close(v.cpu().norm(), G[f"{tag}.G.grad_norm.{n}"], BF, f"G grad norm {n}")
+    print(f"bf16 path, {tag}: worst critic-gradient error {worst:.2e}")
+
+
 def test_full_step_streams_and_prefetch_are_bit_exact():
     """full_step (own stream, CU-masked streams beside the second-order sweeps, next fake batch and the
     generator step's forward made ahead, one-batch lookahead across steps) must give exactly the bits
