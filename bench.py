@@ -113,6 +113,41 @@ def bench_train_wgan(dev, steps, warmup, device_rng, drop_rate):
     return steps * N_CRITIC * B_PER_GPU / dt, dt / steps * 1e3
 
 
+def bench_attention(steps, warmup):
+    """BASELINE config 5's kernel: MaskedMultiheadAttention (transformer.py:196-282) forward + backward at the
+    TenGAN shape (batch 16, L = 512, embed 64, 4 heads; tengan_config.py:7-12) with the causal and padding
+    masks, through the module surface.  One JSON line of its own; not the headline metric."""
+    import common
+    import transformer as T
+    dev = torch.device("cuda", 0)
+    N, L_, E, H = 16, 512, 64, 4
+    c = common.attention_case(1310, N, L_, E, H)
+    m = T.MaskedMultiheadAttention(E, H).to(dev)
+    q, k, v = (c[n].to(dev).requires_grad_(True) for n in "qkv")
+    am, pm, dy = T.create_causal_mask(L_).to(dev), T.create_padding_mask(c["tokens"]).to(dev), c["dy"].to(dev)
+    params = [q, k, v, m.in_proj_weight, m.in_proj_bias, m.fc_out.weight, m.fc_out.bias]
+
+    def step():
+        y = m(v, k, q, attn_mask=am, src_key_padding_mask=pm)
+        torch.autograd.grad(y, params, dy)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    D = E // H
+    core = 2.0 * N * H * L_ * L_ * D * (2 + 4)          # forward: QK^T, PV; backward: dP, dQ, dK, dV
+    proj = 2.0 * N * L_ * (3 * E * 3 * E + E * E) * 3   # in / out projections, forward + two backward products
+    print(json.dumps({"metric": "MaskedMultiheadAttention forward+backward sequences/sec (TenGAN shape)",
+                      "value": N / dt, "unit": "sequences/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+                      "ms_per_step": dt * 1e3, "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+                      "config": {"workload": "attention fwd+bwd, batch 16, L=512, embed 64, 4 heads, causal + padding masks"},
+                      "achieved_tflops": (core + proj) / dt / 1e12, "peak_tflops": FP32_PEAK_TFLOPS}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,12 +159,19 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="f32 (default, the headline): exact-fp32 MFMA everywhere; bf16: bf16 operands / fp32 accumulation "
                          "in the critic's input-layer products (the 2e-2 path)")
+    ap.add_argument("--variant", default="wgan_gp", choices=["wgan_gp", "attention"],
+                    help="wgan_gp (default): the WGAN-GP step; attention: the transformer.py attention module alone")
     ap.add_argument("--path", default="trainer", choices=["trainer", "train_wgan"],
                     help="which path `value` is measured on: WGANGPTrainer.full_step on device-resident batches "
                          "(default, the headline) or the drop-in train_wgan() loop of wgan_gp.py on a CPU loader; "
                          "the other one is reported beside it on one GPU")
     a = ap.parse_args()
 
+    if a.variant == "attention":
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
+        bench_attention(a.steps, a.warmup)
+        return
     from s2g import lib
     from s2g.parallel import init_from_env
     from s2g.trainer import WGANGPTrainer

@@ -296,6 +296,24 @@ int s2g_bn_lrelu_bwd_fused(const float* y, const float* dy, const float* xhat, c
 int s2g_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
              int step, float gscale, void* stream);
 
+/* ---- attention core of MaskedMultiheadAttention.forward (transformer.py:243-274) and its autograd.
+ * Q, K, V: [N, T, H, D] views with row stride ld (the three chunks of the fused in-projection, :235-241),
+ * out / dO: [N, T, H D] with row stride ldo, P and dS: [N, H, T, T].  The reference's conventions are kept:
+ * energy <- -1e3 (finite) where attn_mask[q][k] == 0 ([T, T] floats, optional) and where pad_mask[n][k] == 0
+ * ([N, T] floats, optional; the reference's helper puts 1 at PAD positions, so the NON-pad keys are filled),
+ * softmax(energy * scale) with scale = 1 / sqrt(embed_size).  D % 16 == 0, D <= 64, T <= 2048. */
+typedef struct S2GAttn {
+  int N, H, T, D;
+  long ld, ldo;
+  float scale;
+} S2GAttn;
+int s2g_attention_fwd(const float* Q, const float* K, const float* V, const float* attn_mask, const float* pad_mask,
+                      float* out, float* P, const S2GAttn* dims, void* stream);
+/* gradients of the above given dO: dQ, dK, dV (layout and stride of Q); dS is scratch [N, H, T, T] */
+int s2g_attention_bwd(const float* Q, const float* K, const float* V, const float* attn_mask, const float* pad_mask,
+                      const float* P, const float* dO, float* dS, float* dQ, float* dK, float* dV, const S2GAttn* dims,
+                      void* stream);
+
 /* ---- streams.  No counterpart in the reference (its step is one serial autograd graph,
  * wgan_gp.py:297-317): the second-order sweeps of the penalty run one workgroup per sequence and
  * occupy B of the 256 CUs, so the host runs the work that does not depend on them on a second HIP

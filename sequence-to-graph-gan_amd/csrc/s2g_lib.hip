@@ -7,6 +7,7 @@
 #include "gemm_bf16.hip"
 #include "sampler.hip"
 #include "elementwise.hip"
+#include "attention.hip"
 #include <math.h>
 #include <mutex>
 
@@ -511,6 +512,31 @@ int s2g_adam(float* p, const float* g, float* m, float* v, long n, float lr, flo
   hipLaunchKernelGGL(s2g_k_adam, dim3(blocks), dim3(256), 0, ST(stream), p, g, m, v, n, b1, b2, eps, step_size,
                      inv_sqrt_bc2, gscale);
   return LAUNCH_OK();
+}
+
+struct S2GAttn {        // mirrors include/s2g.h
+  int N, H, T, D;
+  long ld, ldo;
+  float scale;
+};
+static int attn_dims(const S2GAttn* a, AttnDims* d) {
+  if (!a || a->N <= 0 || a->H <= 0 || a->T <= 0 || a->T > 2048 || a->D <= 0 || a->D > ATT_MAXD || (a->D & 15)) return -1;
+  if (a->ld < (long)a->H * a->D || a->ldo < (long)a->H * a->D || !(a->scale > 0.0f)) return -1;
+  *d = AttnDims{a->N, a->H, a->T, a->D, a->ld, a->ldo, a->scale};
+  return 0;
+}
+int s2g_attention_fwd(const float* Q, const float* K, const float* V, const float* attn_mask, const float* pad_mask,
+                      float* out, float* P, const S2GAttn* dims, void* stream) {
+  AttnDims d;
+  if (!Q || !K || !V || !out || attn_dims(dims, &d) != 0) return -1;
+  return s2g_launch_attn_fwd(Q, K, V, attn_mask, pad_mask, out, P, d, ST(stream));
+}
+int s2g_attention_bwd(const float* Q, const float* K, const float* V, const float* attn_mask, const float* pad_mask,
+                      const float* P, const float* dO, float* dS, float* dQ, float* dK, float* dV, const S2GAttn* dims,
+                      void* stream) {
+  AttnDims d;
+  if (!Q || !K || !V || !P || !dO || !dS || !dQ || !dK || !dV || attn_dims(dims, &d) != 0) return -1;
+  return s2g_launch_attn_bwd(Q, K, V, attn_mask, pad_mask, P, dO, dS, dQ, dK, dV, d, ST(stream));
 }
 
 int s2g_stream_create_cu_mask(const unsigned* mask, int nwords, void** stream_out) {

@@ -34,6 +34,10 @@ class S2GHead(ctypes.Structure):
                 ("inv_wsum", F), ("w0", F), ("w1", F)]
 
 
+class S2GAttn(ctypes.Structure):
+    _fields_ = [("N", I), ("H", I), ("T", I), ("D", I), ("ld", L), ("ldo", L), ("scale", F)]
+
+
 class S2GReduce(ctypes.Structure):
     _fields_ = [("slabs", P), ("slab", L), ("out", P), ("nslab", I), ("rows", I), ("cols", I)]
 
@@ -98,6 +102,8 @@ SIGNATURES = {
     "s2g_bn_lrelu_fwd_fused": [P, P, P, P, P, F, F, I, P, P, P, I, I, P],
     "s2g_bn_lrelu_bwd_fused": [P, P, P, P, P, P, P, P, I, I, P],
     "s2g_adam": [P, P, P, P, L, F, F, F, F, I, F, P],
+    "s2g_attention_fwd": [P, P, P, P, P, P, P, ctypes.POINTER(S2GAttn), P],
+    "s2g_attention_bwd": [P, P, P, P, P, P, P, P, P, P, P, ctypes.POINTER(S2GAttn), P],
     "s2g_stream_create_cu_mask": [P, I, P],
     "s2g_stream_destroy": [P],
 }

@@ -448,6 +448,39 @@ def g10_generate_fake_data(ref):
     save("g10_generate_fake_data.pt", out)
 
 
+def g11_attention(ref):
+    """MaskedMultiheadAttention (transformer.py:196-282) of the imported reference: outputs and the gradients of
+    inputs and parameters for a given upstream gradient, without masks, with the reference's own
+    create_causal_mask / create_padding_mask, and with batch_first=True."""
+    import transformer as T_ref                   # /root/reference/transformer.py (first on sys.path)
+    assert T_ref.__file__.startswith("/root/reference")
+    out = {}
+    for tag, (seed, N, T, E, H) in {"small": (1301, 3, 20, 32, 2), "selftest": (1302, 8, 50, 64, 4),
+                                    "ragged": (1303, 2, 37, 64, 1)}.items():
+        c = common.attention_case(seed, N, T, E, H)
+        for mode in ("nomask", "masks", "batch_first"):
+            m = T_ref.MaskedMultiheadAttention(E, H, batch_first=(mode == "batch_first"))
+            with torch.no_grad():
+                m.in_proj_weight.copy_(c["in_w"]); m.in_proj_bias.copy_(c["in_b"])
+                m.fc_out.weight.copy_(c["out_w"]); m.fc_out.bias.copy_(c["out_b"])
+            q, k, v = (c[n].clone().requires_grad_(True) for n in "qkv")
+            am = T_ref.create_causal_mask(T) if mode != "nomask" else None
+            pm = T_ref.create_padding_mask(c["tokens"]) if mode != "nomask" else None
+            if mode == "batch_first":
+                # the module transposes (0, 1) first: feed [T, N, E] so that the same problem results
+                y = m(v.transpose(0, 1), k.transpose(0, 1), q.transpose(0, 1), attn_mask=am, src_key_padding_mask=pm)
+                y = y.transpose(0, 1)
+            else:
+                y = m(v, k, q, attn_mask=am, src_key_padding_mask=pm)
+            grads = torch.autograd.grad(y, [q, k, v, m.in_proj_weight, m.in_proj_bias, m.fc_out.weight, m.fc_out.bias],
+                                        c["dy"])
+            key = f"{tag}.{mode}"
+            out[f"{key}.y"] = y.detach().clone()
+            for n, gv in zip(("dq", "dk", "dv", "d_in_w", "d_in_b", "d_out_w", "d_out_b"), grads):
+                out[f"{key}.{n}"] = gv.clone()
+    save("g11_attention.pt", out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
@@ -455,7 +488,7 @@ def main():
     a = ap.parse_args()
     torch.manual_seed(0)
     ref = import_reference()
-    todo = [g1_sampler, g2_generator, g3_critic, g4_gp, g5_ce, g6_adam, g7_full_step, g10_generate_fake_data]
+    todo = [g1_sampler, g2_generator, g3_critic, g4_gp, g5_ce, g6_adam, g7_full_step, g10_generate_fake_data, g11_attention]
     if a.full:
         todo += [g8_full_size, g9_full_step_full_size]
     for fn in todo:
