@@ -148,6 +148,44 @@ def bench_attention(steps, warmup):
                       "achieved_tflops": (core + proj) / dt / 1e12, "peak_tflops": FP32_PEAK_TFLOPS}), flush=True)
 
 
+def bench_wgan_clip(steps, warmup):
+    """BASELINE config 4: the weight-clipping WGAN variant (reference wgan.py) at L = 1024, B = 128: one step =
+    one critic update of CWGAN.train_step (:174-198: D(real tokens), G(noise).detach(), D(fake, 100 steps),
+    Wasserstein loss, Adam, clamp), dropout 0.3, device-resident batches.  The reference's generator branch
+    cannot run (undefined self.loss, :214), so the critic update is what there is to measure.  One JSON line
+    of its own; not the headline metric."""
+    import common
+    from s2g.wgan_clip import ClipCriticEngine, ClipGeneratorEngine
+    dev = torch.device("cuda", 0)
+    Vc, Bc, Lc = 175, 128, 1024
+    pd, pg = common.wgan_clip_params(1701, Vc)
+    D, G = ClipCriticEngine(Vc, 2, dev, dropout=0.3), ClipGeneratorEngine(Vc, 3, dev)
+    D.load(pd); G.load(pg)
+    pool = []
+    for i in range(4):
+        tok, lab, ln = common.batch(1710 + i, Bc, Lc, vocab=Vc, lengths=[Lc] * Bc)
+        pool.append((tok.to(torch.int32).to(dev).contiguous(), lab.to(dev), ln.to(torch.int32).to(dev),
+                     torch.randint(0, Vc, (Bc, 100), generator=common.gen(1720 + i)).to(torch.int32).to(dev)))
+
+    def step(k):
+        tok, lab, ln, noise = pool[k % len(pool)]
+        fake = G.forward(noise, lab, 0.5)
+        D.critic_step(tok, lab, ln, Lc, fake, 2e-4, 0.5, 0.999, 0.1)
+    for k in range(warmup):
+        step(k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(warmup + k)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    print(json.dumps({"metric": "weight-clipping WGAN critic-update sequences/sec at V=175 L=1024 B=128",
+                      "value": Bc / dt, "unit": "sequences/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+                      "ms_per_step": dt * 1e3, "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+                      "config": {"workload": "wgan.py critic update: D(real L=1024) + G forward + D(fake L=100) + backward + "
+                                             "Adam + clamp, B=128, dropout 0.3"}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -159,8 +197,9 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="f32 (default, the headline): exact-fp32 MFMA everywhere; bf16: bf16 operands / fp32 accumulation "
                          "in the critic's input-layer products (the 2e-2 path)")
-    ap.add_argument("--variant", default="wgan_gp", choices=["wgan_gp", "attention"],
-                    help="wgan_gp (default): the WGAN-GP step; attention: the transformer.py attention module alone")
+    ap.add_argument("--variant", default="wgan_gp", choices=["wgan_gp", "attention", "wgan_clip"],
+                    help="wgan_gp (default): the WGAN-GP step; attention: the transformer.py attention module alone; "
+                         "wgan_clip: the critic update of the weight-clipping variant (wgan.py) at L=1024, B=128")
     ap.add_argument("--path", default="trainer", choices=["trainer", "train_wgan"],
                     help="which path `value` is measured on: WGANGPTrainer.full_step on device-resident batches "
                          "(default, the headline) or the drop-in train_wgan() loop of wgan_gp.py on a CPU loader; "
@@ -171,6 +210,11 @@ def main():
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
         bench_attention(a.steps, a.warmup)
+        return
+    if a.variant == "wgan_clip":
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
+        bench_wgan_clip(a.steps, a.warmup)
         return
     from s2g import lib
     from s2g.parallel import init_from_env

@@ -270,9 +270,11 @@ int s2g_lrelu_bwd(const float* y, float* dy, long n, void* stream);
 /* inter-layer dropout of nn.LSTM(175, 50, 2, dropout=p) in train mode (wgan_gp.py:189): uniform draws
  * u[rows][52] -> multiplier (u >= p) / (1 - p) in place, columns 50 and 51 (row padding) -> 0 */
 int s2g_dropout_mask(float* u, long rows, float p, void* stream);
-/* the same mask [rows][52] with the uniforms drawn inside the kernel (one write pass, no tensor of draws) */
-int s2g_dropout_mask_rng(float* mask, long rows, float p, unsigned long long seed, unsigned long long offset,
-                         void* stream);
+/* such a mask [rows][width] with the uniforms drawn inside the kernel (one write pass, no tensor of draws):
+ * columns < live_cols hold (u >= p) / (1 - p), the padding columns 0; width % 4 == 0 (52 / 50 for the H = 50
+ * critic, 64 / 64 for the H = 64 critic of wgan.py) */
+int s2g_dropout_mask_rng(float* mask, long rows, int width, int live_cols, float p, unsigned long long seed,
+                         unsigned long long offset, void* stream);
 int s2g_bn_stats(const float* x, float* stats, int B, int F, void* stream);
 int s2g_bn_lrelu_apply(const float* x, const float* stats, float n_global, const float* gamma,
                        const float* beta, float* run_mean, float* run_var, float eps, float momentum,
@@ -313,6 +315,42 @@ int s2g_attention_fwd(const float* Q, const float* K, const float* V, const floa
 int s2g_attention_bwd(const float* Q, const float* K, const float* V, const float* attn_mask, const float* pad_mask,
                       const float* P, const float* dO, float* dS, float* dQ, float* dK, float* dV, const S2GAttn* dims,
                       void* stream);
+
+/* ---- weight-clipping WGAN variant (reference wgan.py).  Hidden size 64 throughout (wgan.py:50, 96); buffers
+ * are [rows, .] with sequence n owning rows [n T, n T + len_n).
+ * One LSTM layer over all its steps (nn.LSTM(64, 64, ...) of wgan.py:58, 100): pin [rows, 256] = x W_ih^T + b_ih + b_hh
+ * (a batched product done beforehand), whh the torch parameter [256, 64]; saves the activated gates [rows, 256]
+ * (torch order i|f|g|o), the cell states [rows, 64] and writes the hidden states hout [rows, 64] (zeros beyond a
+ * sequence's length, as pad_packed_sequence returns them, wgan.py:114).  lengths NULL: every sequence has T steps.
+ * out_mask / hdrop (optional): hdrop = hout * out_mask, the next layer's input under nn.LSTM's dropout. */
+int s2g_lstm64_fwd(const float* pin, const float* whh, const int* lengths, int nseq, int T, float* gates, float* cst,
+                   float* hout, const float* out_mask, float* hdrop, void* stream);
+/* its autograd: dh_in [rows, 64] = gradient reaching every h_t from above -> delta [rows, 256], the gradient of
+ * the gate pre-activations (zeros beyond the length); weight / input gradients are batched products of delta. */
+int s2g_lstm64_bwd(const float* dh_in, const float* whh, const int* lengths, int nseq, int T, const float* gates,
+                   const float* cst, float* delta, void* stream);
+/* x [rows, 64] = (emb[token] | lab_emb[label of the sequence]): label_embedding / RelaxedEmbedding lookup + concat
+ * (wgan.py:39-42, 107-111); soft != 0: columns 0..31 already hold y @ emb (the matmul branch, :45). */
+int s2g_embed_concat(const int* tokens, const float* emb, int V, const long long* labels, const float* lab_emb,
+                     int n_classes, int T, long rows, int soft, float* x, void* stream);
+/* gradients of the two lookups from dx [rows, 64] (live rows only) */
+int s2g_embed_grad_tokens(const int* tokens, const int* lengths, int T, long rows, int V, const float* dx, float* demb,
+                          int accumulate, void* stream);
+int s2g_embed_grad_labels(const long long* labels, const int* lengths, int T, int B, int n_classes, const float* dx,
+                          float* dlab, int accumulate, void* stream);
+/* Attention pooling + output Linear of the critic (wgan.py:82-89, 116-118) over the first Tp = max(lengths) steps:
+ * pre [rows, 64] = out Wa^T + ba on entry, tanh(pre) on return; weights [nseq, T], pooled [nseq, 64], dval [nseq]. */
+int s2g_attnpool_fwd(float* pre, const float* out, const float* wc, const float* wl, const float* bl, int nseq, int T,
+                     int Tp, float* weights, float* pooled, float* dval, void* stream);
+/* its autograd for dD [nseq]: a_dpre (tanh(pre) on entry) <- d(pre); dout [rows, 64] = the direct part of d(out);
+ * dwc_part [nseq, 64] = every sequence's share of d(context_vector.weight). */
+int s2g_attnpool_bwd(float* a_dpre, const float* out, const float* wc, const float* wl, const float* weights,
+                     const float* dD, int nseq, int T, int Tp, float* dout, float* dwc_part, void* stream);
+/* d_loss = -(mean(D_real) - mean(D_fake)) (wgan.py:145-147) for dval = [real B | fake B], and its derivative dD */
+int s2g_wasserstein_loss(const float* dval, int B, float* dD, float* loss, void* stream);
+/* p <- clamp(p, -clip, clip) (wgan.py:155-158) */
+int s2g_clamp(float* p, long n, float clip, void* stream);
+int s2g_mul_inplace(float* a, const float* b, long n, void* stream);
 
 /* ---- streams.  No counterpart in the reference (its step is one serial autograd graph,
  * wgan_gp.py:297-317): the second-order sweeps of the penalty run one workgroup per sequence and

@@ -1,0 +1,315 @@
+// LSTM sweeps for the weight-clipping WGAN variant (reference wgan.py: nn.LSTM(64, 64, num_layers) in
+// Generator :58 and Discriminator :100, hidden_dim = 64) and its attention pooling (wgan.py:75-89).
+// One layer per launch over all its time steps, one workgroup of 256 threads per sequence: thread j owns gate
+// row j (torch order: i | f | g | o blocks of 64) with its 64 recurrent weights in registers; the input part
+// x_t W_ih^T + b_ih + b_hh of every step is a batched GEMM done beforehand (it does not depend on the
+// recurrence), and the weight gradients are batched GEMMs over the saved gate gradients afterwards.
+// Rows: sequence n owns rows [n * rows_per_seq, n * rows_per_seq + len_n) of every [rows, .] buffer; rows at or
+// beyond its length are written as zeros where a later batched product reads them (pad_packed_sequence
+// semantics, wgan.py:112-114).
+#pragma once
+#include "s2g_common.h"
+
+#define X_H 64
+#define X_G 256
+
+// gates [rows, 256] (activated i, f, g, o), cst [rows, 64] (cell state), hout [rows, 64].
+// out_mask (optional, [rows, 64]): hout is ALSO written multiplied by it to hdrop (the next layer's input under
+// nn.LSTM's inter-layer dropout); the recurrence itself uses the undropped h.
+extern "C" __global__ __launch_bounds__(X_G) void s2g_k_lstm64_fwd(const float* __restrict__ pin,
+                                                                   const float* __restrict__ whh,
+                                                                   const int* __restrict__ lengths, int T,
+                                                                   float* __restrict__ gates, float* __restrict__ cst,
+                                                                   float* __restrict__ hout,
+                                                                   const float* __restrict__ out_mask,
+                                                                   float* __restrict__ hdrop) {
+  __shared__ __attribute__((aligned(16))) float hs[X_H];
+  __shared__ float gs[X_G];
+  const int n = blockIdx.x, j = threadIdx.x;
+  const int len = lengths ? min(max(lengths[n], 0), T) : T;
+  float w[X_H];
+#pragma unroll
+  for (int k = 0; k < X_H; ++k) w[k] = whh[j * X_H + k];
+  if (j < X_H) hs[j] = 0.0f;
+  const size_t r0 = (size_t)n * T;
+  const int q = j >> 6;                        // gate block: 0 i, 1 f, 2 g (tanh), 3 o
+  float c = 0.0f;
+  float nxt = len > 0 ? pin[r0 * X_G + j] : 0.0f;
+  __syncthreads();
+  for (int t = 0; t < len; ++t) {
+    float a = nxt;
+    if (t + 1 < len) nxt = pin[(r0 + t + 1) * X_G + j];          // next step's input part, ahead of its use
+    const float4* h4 = reinterpret_cast<const float4*>(hs);
+#pragma unroll
+    for (int k = 0; k < X_H / 4; ++k) {
+      const float4 hv = h4[k];
+      a = fmaf(w[4 * k], hv.x, a); a = fmaf(w[4 * k + 1], hv.y, a);
+      a = fmaf(w[4 * k + 2], hv.z, a); a = fmaf(w[4 * k + 3], hv.w, a);
+    }
+    const float g = (q == 2) ? tanhf(a) : 1.0f / (1.0f + expf(-a));
+    gs[j] = g;
+    gates[(r0 + t) * X_G + j] = g;
+    __syncthreads();
+    if (j < X_H) {
+      c = fmaf(gs[X_H + j], c, gs[j] * gs[2 * X_H + j]);
+      const float h = gs[3 * X_H + j] * tanhf(c);
+      hs[j] = h;
+      cst[(r0 + t) * X_H + j] = c;
+      hout[(r0 + t) * X_H + j] = h;
+      if (hdrop) hdrop[(r0 + t) * X_H + j] = out_mask ? h * out_mask[(r0 + t) * X_H + j] : h;
+    }
+    __syncthreads();
+  }
+  // rows beyond the sequence: zeros (what pad_packed_sequence returns, and what the batched products must see)
+  for (size_t e = (size_t)len * X_H + j; e < (size_t)T * X_H; e += X_G) {
+    hout[r0 * X_H + e] = 0.0f;
+    if (hdrop) hdrop[r0 * X_H + e] = 0.0f;
+  }
+}
+
+// Reverse sweep of one layer.  dh_in [rows, 64]: gradient reaching h_t from above (the attention pooling or
+// the next layer's input gradient; already multiplied by that layer's dropout mask where one applies).
+// delta [rows, 256]: gradient wrt the gate pre-activations (rows beyond the length zeroed).
+extern "C" __global__ __launch_bounds__(X_G) void s2g_k_lstm64_bwd(const float* __restrict__ dh_in,
+                                                                   const float* __restrict__ whh,
+                                                                   const int* __restrict__ lengths, int T,
+                                                                   const float* __restrict__ gates,
+                                                                   const float* __restrict__ cst,
+                                                                   float* __restrict__ delta) {
+  __shared__ float ds[X_G];
+  __shared__ float part[4][X_H];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int len = lengths ? min(max(lengths[n], 0), T) : T;
+  const int k = tid & 63, blk = tid >> 6;
+  // W_hh^T slice: thread (k, blk) sums over gate rows blk*64 .. blk*64+63 of column k
+  float w[X_H];
+#pragma unroll
+  for (int u = 0; u < X_H; ++u) w[u] = whh[(blk * X_H + u) * X_H + k];
+  ds[tid] = 0.0f;
+  const size_t r0 = (size_t)n * T;
+  float dc = 0.0f;
+  __syncthreads();
+  for (int t = len - 1; t >= 0; --t) {
+    float s = 0.0f;
+#pragma unroll
+    for (int u = 0; u < X_H; ++u) s = fmaf(w[u], ds[blk * X_H + u], s);
+    part[blk][k] = s;
+    __syncthreads();
+    if (tid < X_H) {
+      const float dh = dh_in[(r0 + t) * X_H + tid] + ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]));
+      const float* gr = gates + (r0 + t) * X_G;
+      const float gi = gr[tid], gf = gr[X_H + tid], gg = gr[2 * X_H + tid], go = gr[3 * X_H + tid];
+      const float ct = cst[(r0 + t) * X_H + tid];
+      const float cprev = t > 0 ? cst[(r0 + t - 1) * X_H + tid] : 0.0f;
+      const float tc = tanhf(ct);
+      const float dct = fmaf(dh * go, 1.0f - tc * tc, dc);
+      const float di = dct * gg * gi * (1.0f - gi);
+      const float df = dct * cprev * gf * (1.0f - gf);
+      const float dg = dct * gi * (1.0f - gg * gg);
+      const float dO = dh * tc * go * (1.0f - go);
+      dc = dct * gf;
+      float* dr = delta + (r0 + t) * X_G;
+      dr[tid] = di; dr[X_H + tid] = df; dr[2 * X_H + tid] = dg; dr[3 * X_H + tid] = dO;
+      ds[tid] = di; ds[X_H + tid] = df; ds[2 * X_H + tid] = dg; ds[3 * X_H + tid] = dO;
+    }
+    __syncthreads();
+  }
+  for (size_t e = (size_t)len * X_G + tid; e < (size_t)T * X_G; e += X_G) delta[r0 * X_G + e] = 0.0f;
+}
+
+// x[row] = (emb[token[row]] | label_emb[label[n]])  (wgan.py:107-111 with the lookup branch of RelaxedEmbedding,
+// :39-42); token ids clamped to the table.  soft != 0: the first 32 columns already hold y @ emb (the matmul
+// branch, :45) and only the label half is written.
+extern "C" __global__ void s2g_k_embed_concat(const int* __restrict__ tokens, const float* __restrict__ emb, int V,
+                                              const long long* __restrict__ labels, const float* __restrict__ lab_emb,
+                                              int n_classes, int T, long rows, int soft, float* __restrict__ x) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= rows * 64) return;
+  const long r = e >> 6;
+  const int c = (int)(e & 63);
+  if (c < 32) {
+    if (!soft) x[e] = emb[(long)min(max(tokens[r], 0), V - 1) * 32 + c];
+  } else {
+    const long long l = min(max(labels[r / T], 0LL), (long long)n_classes - 1);
+    x[e] = lab_emb[l * 32 + (c - 32)];
+  }
+}
+
+// gradient of the lookup branch: demb[token[row]] += dx[row][0:32] for live rows (t < len); one workgroup per
+// vocabulary entry scans the tokens (V workgroups, deterministic order of additions inside a thread column).
+extern "C" __global__ __launch_bounds__(256) void s2g_k_embed_grad_tokens(const int* __restrict__ tokens,
+                                                                          const int* __restrict__ lengths, int T,
+                                                                          long rows, int V, const float* __restrict__ dx,
+                                                                          float* __restrict__ demb, int accumulate) {
+  __shared__ float red[8][32];
+  const int v = blockIdx.x, c = threadIdx.x & 31, g = threadIdx.x >> 5;
+  float s = 0.0f;
+  for (long r = g; r < rows; r += 8) {
+    const int tok = min(max(tokens[r], 0), V - 1);
+    if (tok == v && (int)(r % T) < lengths[r / T]) s += dx[r * 64 + c];
+  }
+  red[g][c] = s;
+  __syncthreads();
+  if (g == 0) {
+    float t = 0.0f;
+    for (int k = 0; k < 8; ++k) t += red[k][c];
+    demb[v * 32 + c] = accumulate ? demb[v * 32 + c] + t : t;
+  }
+}
+
+// gradient of the label half: dlab[l] (+)= sum over sequences with label l and live rows of dx[row][32:64]
+extern "C" __global__ __launch_bounds__(256) void s2g_k_embed_grad_labels(const long long* __restrict__ labels,
+                                                                          const int* __restrict__ lengths, int T, int B,
+                                                                          const float* __restrict__ dx,
+                                                                          float* __restrict__ dlab, int accumulate) {
+  __shared__ float red[8][32];
+  const int l = blockIdx.x, c = threadIdx.x & 31, g = threadIdx.x >> 5;
+  float s = 0.0f;
+  for (int b = 0; b < B; ++b) {
+    if (labels[b] != l) continue;
+    const int len = lengths ? min(lengths[b], T) : T;
+    for (int t = g; t < len; t += 8) s += dx[((long)b * T + t) * 64 + 32 + c];
+  }
+  red[g][c] = s;
+  __syncthreads();
+  if (g == 0) {
+    float t = 0.0f;
+    for (int k = 0; k < 8; ++k) t += red[k][c];
+    dlab[l * 32 + c] = accumulate ? dlab[l * 32 + c] + t : t;
+  }
+}
+
+// ---- attention pooling (wgan.py:82-89, 116-118) over Tp = the longest sequence of the batch (what
+// pad_packed_sequence returns): scores_t = wc . tanh(pre_t), pre = out Wa^T + ba (a batched GEMM);
+// weights = softmax over ALL Tp positions (padded rows hold out = 0, so their score is wc . tanh(ba): they
+// take part in the softmax, as in the reference); pooled = sum_t weights_t out_t; D = wl . pooled + bl.
+// One workgroup per sequence.  Saves tanh(pre) in place, the weights and pooled for the backward pass.
+extern "C" __global__ __launch_bounds__(256) void s2g_k_attnpool_fwd(float* __restrict__ pre, const float* __restrict__ out,
+                                                                     const float* __restrict__ wc,
+                                                                     const float* __restrict__ wl,
+                                                                     const float* __restrict__ bl, int T, int Tp,
+                                                                     float* __restrict__ weights,
+                                                                     float* __restrict__ pooled, float* __restrict__ dval) {
+  extern __shared__ float sc[];             // [Tp] scores, then weights
+  __shared__ float red[4][X_H];
+  __shared__ float stat[2];
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t r0 = (size_t)n * T;
+  const float wk = wc[lane];
+  for (int t = wave; t < Tp; t += 4) {
+    const float a = tanhf(pre[(r0 + t) * X_H + lane]);
+    pre[(r0 + t) * X_H + lane] = a;
+    float s = wk * a;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
+    if (lane == 0) sc[t] = s;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float mx = -INFINITY;
+    for (int t = lane; t < Tp; t += 64) mx = fmaxf(mx, sc[t]);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.0f;
+    for (int t = lane; t < Tp; t += 64) sum += expf(sc[t] - mx);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) sum += __shfl_xor(sum, o);
+    if (lane == 0) { stat[0] = mx; stat[1] = 1.0f / sum; }
+  }
+  __syncthreads();
+  float acc = 0.0f;
+  for (int t = wave; t < Tp; t += 4) {
+    const float wgt = expf(sc[t] - stat[0]) * stat[1];
+    if (lane == 0) weights[(size_t)n * T + t] = wgt;
+    acc = fmaf(wgt, out[(r0 + t) * X_H + lane], acc);
+  }
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0) {
+    const float p = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    pooled[(size_t)n * X_H + lane] = p;
+    float s = wl[lane] * p;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
+    if (lane == 0) dval[n] = s + bl[0];
+  }
+}
+
+// backward of the pooling for d(loss)/d(D_n) = dD[n]: d(out) (direct part: weights_t * dpooled), dpre =
+// ds_t * wc * (1 - a^2) written over a, and this sequence's share of d(wc); d(wl), d(bl) follow from pooled.
+extern "C" __global__ __launch_bounds__(256) void s2g_k_attnpool_bwd(float* __restrict__ a_dpre, const float* __restrict__ out,
+                                                                     const float* __restrict__ wc,
+                                                                     const float* __restrict__ wl,
+                                                                     const float* __restrict__ weights,
+                                                                     const float* __restrict__ dD, int T, int Tp,
+                                                                     float* __restrict__ dout, float* __restrict__ dwc_part) {
+  extern __shared__ float dw[];             // [Tp] d(weights), then d(scores)
+  __shared__ float red[4][X_H];
+  __shared__ float dot_s;
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t r0 = (size_t)n * T;
+  const float dp = dD[n] * wl[lane];                       // d(pooled)
+  for (int t = wave; t < Tp; t += 4) {
+    float s = dp * out[(r0 + t) * X_H + lane];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
+    if (lane == 0) dw[t] = s;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float d = 0.0f;
+    for (int t = lane; t < Tp; t += 64) d = fmaf(weights[(size_t)n * T + t], dw[t], d);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) d += __shfl_xor(d, o);
+    if (lane == 0) dot_s = d;
+  }
+  __syncthreads();
+  const float wk = wc[lane];
+  float acc = 0.0f;
+  for (int t = wave; t < Tp; t += 4) {
+    const float wgt = weights[(size_t)n * T + t];
+    const float dsc = wgt * (dw[t] - dot_s);               // softmax backward
+    const float a = a_dpre[(r0 + t) * X_H + lane];
+    acc = fmaf(dsc, a, acc);                               // d(wc)
+    a_dpre[(r0 + t) * X_H + lane] = dsc * wk * (1.0f - a * a);
+    dout[(r0 + t) * X_H + lane] = wgt * dp;
+  }
+  for (int t = Tp + wave; t < T; t += 4) {                 // rows the pooling never saw
+    a_dpre[(r0 + t) * X_H + lane] = 0.0f;
+    dout[(r0 + t) * X_H + lane] = 0.0f;
+  }
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0) dwc_part[(size_t)n * X_H + lane] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+// critic loss of the weight-clipping WGAN (wgan.py:145-147, 189): values = [real B | fake B];
+// loss = -(mean(real) - mean(fake)); dD = (-1/B, +1/B).  One workgroup.
+extern "C" __global__ __launch_bounds__(256) void s2g_k_wasserstein_loss(const float* __restrict__ dval, int B,
+                                                                         float* __restrict__ dD, float* __restrict__ loss) {
+  __shared__ float red[2][256];
+  float sr = 0.0f, sf = 0.0f;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    sr += dval[b]; sf += dval[B + b];
+    dD[b] = -1.0f / B; dD[B + b] = 1.0f / B;
+  }
+  red[0][threadIdx.x] = sr; red[1][threadIdx.x] = sf;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.0f, c = 0.0f;
+    for (int k = 0; k < 256; ++k) { a += red[0][k]; c += red[1][k]; }
+    loss[0] = -(a / B - c / B);
+  }
+}
+
+// p <- clamp(p, -clip, clip): the weight clipping after the critic's optimizer step (wgan.py:155-158, 198)
+extern "C" __global__ void s2g_k_clamp(float* __restrict__ p, long n, float clip) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = fminf(fmaxf(p[i], -clip), clip);
+}
+
+// a[i] *= b[i]  (an input gradient times the dropout mask of the layer it came through)
+extern "C" __global__ void s2g_k_mul_inplace(float* __restrict__ a, const float* __restrict__ b, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] *= b[i];
+}

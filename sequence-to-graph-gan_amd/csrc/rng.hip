@@ -51,19 +51,20 @@ extern "C" __global__ __launch_bounds__(256) void s2g_k_rng_fill(float* __restri
     if (4 * g + k < n) out[4 * g + k] = v[k];
 }
 
-// Dropout multipliers of the critic's layer-0 outputs, mask[rows][52]: (u >= p) / (1 - p) in columns
-// 0..49, zero in the two padding columns.  One Philox call per 16-byte store.
+// Dropout multipliers of an LSTM layer's outputs, mask[rows][width]: (u >= p) / (1 - p) in columns
+// 0..live-1, zero in the padding columns live..width-1 (width % 4 == 0; the critic's H = 50 rows are padded
+// to 52).  One Philox call per 16-byte store.
 extern "C" __global__ __launch_bounds__(256) void s2g_k_dropout_mask_rng(float* __restrict__ mask, long n4, float p,
                                                                          float inv_keep, unsigned long long seed,
-                                                                         unsigned long long offset) {
+                                                                         unsigned long long offset, int w4, int live) {
   const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n4) return;
   const Philox4 r = philox4x32_10((unsigned long long)g, offset, seed);
-  const bool last = g % (S2G_MASKW / 4) == S2G_MASKW / 4 - 1;      // columns 48..51: the last two are padding
+  const int c0 = 4 * (int)(g % w4);
   float4 m;
-  m.x = u01(r.x) >= p ? inv_keep : 0.0f;
-  m.y = u01(r.y) >= p ? inv_keep : 0.0f;
-  m.z = last ? 0.0f : (u01(r.z) >= p ? inv_keep : 0.0f);
-  m.w = last ? 0.0f : (u01(r.w) >= p ? inv_keep : 0.0f);
+  m.x = (c0 < live && u01(r.x) >= p) ? inv_keep : 0.0f;
+  m.y = (c0 + 1 < live && u01(r.y) >= p) ? inv_keep : 0.0f;
+  m.z = (c0 + 2 < live && u01(r.z) >= p) ? inv_keep : 0.0f;
+  m.w = (c0 + 3 < live && u01(r.w) >= p) ? inv_keep : 0.0f;
   reinterpret_cast<float4*>(mask)[g] = m;
 }

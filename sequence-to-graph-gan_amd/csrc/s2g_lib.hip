@@ -8,6 +8,7 @@
 #include "sampler.hip"
 #include "elementwise.hip"
 #include "attention.hip"
+#include "lstm64.hip"
 #include <math.h>
 #include <mutex>
 
@@ -52,12 +53,13 @@ int s2g_rng_fill(float* out, long n, int kind, unsigned long long seed, unsigned
   return LAUNCH_OK();
 }
 
-int s2g_dropout_mask_rng(float* mask, long rows, float p, unsigned long long seed, unsigned long long offset,
-                         void* stream) {
+int s2g_dropout_mask_rng(float* mask, long rows, int width, int live_cols, float p, unsigned long long seed,
+                         unsigned long long offset, void* stream) {
   if (!mask || rows <= 0 || !(p >= 0.0f) || !(p < 1.0f) || ((uintptr_t)mask & 15)) return -1;
-  const long n4 = rows * (S2G_MASKW / 4);
+  if (width <= 0 || (width & 3) || live_cols <= 0 || live_cols > width) return -1;
+  const long n4 = rows * (width / 4);
   hipLaunchKernelGGL(s2g_k_dropout_mask_rng, dim3(cdiv(n4, 256)), dim3(256), 0, ST(stream), mask, n4, p,
-                     1.0f / (1.0f - p), seed, offset);
+                     1.0f / (1.0f - p), seed, offset, width / 4, live_cols);
   return LAUNCH_OK();
 }
 
@@ -511,6 +513,77 @@ int s2g_adam(float* p, const float* g, float* m, float* v, long n, float lr, flo
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(s2g_k_adam, dim3(blocks), dim3(256), 0, ST(stream), p, g, m, v, n, b1, b2, eps, step_size,
                      inv_sqrt_bc2, gscale);
+  return LAUNCH_OK();
+}
+
+// ---- weight-clipping WGAN variant (reference wgan.py): hidden size 64
+int s2g_lstm64_fwd(const float* pin, const float* whh, const int* lengths, int nseq, int T, float* gates, float* cst,
+                   float* hout, const float* out_mask, float* hdrop, void* stream) {
+  if (!pin || !whh || !gates || !cst || !hout || nseq <= 0 || T <= 0) return -1;
+  if (out_mask && !hdrop) return -1;
+  hipLaunchKernelGGL(s2g_k_lstm64_fwd, dim3(nseq), dim3(X_G), 0, ST(stream), pin, whh, lengths, T, gates, cst, hout,
+                     out_mask, hdrop);
+  return LAUNCH_OK();
+}
+int s2g_lstm64_bwd(const float* dh_in, const float* whh, const int* lengths, int nseq, int T, const float* gates,
+                   const float* cst, float* delta, void* stream) {
+  if (!dh_in || !whh || !gates || !cst || !delta || nseq <= 0 || T <= 0) return -1;
+  hipLaunchKernelGGL(s2g_k_lstm64_bwd, dim3(nseq), dim3(X_G), 0, ST(stream), dh_in, whh, lengths, T, gates, cst, delta);
+  return LAUNCH_OK();
+}
+int s2g_embed_concat(const int* tokens, const float* emb, int V, const long long* labels, const float* lab_emb,
+                     int n_classes, int T, long rows, int soft, float* x, void* stream) {
+  if (!emb || !labels || !lab_emb || !x || V <= 0 || n_classes <= 0 || T <= 0 || rows <= 0) return -1;
+  if (!soft && !tokens) return -1;
+  hipLaunchKernelGGL(s2g_k_embed_concat, dim3(cdiv(rows * 64, 256)), dim3(256), 0, ST(stream), tokens, emb, V, labels,
+                     lab_emb, n_classes, T, rows, soft, x);
+  return LAUNCH_OK();
+}
+int s2g_embed_grad_tokens(const int* tokens, const int* lengths, int T, long rows, int V, const float* dx, float* demb,
+                          int accumulate, void* stream) {
+  if (!tokens || !lengths || !dx || !demb || T <= 0 || rows <= 0 || V <= 0) return -1;
+  hipLaunchKernelGGL(s2g_k_embed_grad_tokens, dim3(V), dim3(256), 0, ST(stream), tokens, lengths, T, rows, V, dx, demb,
+                     accumulate);
+  return LAUNCH_OK();
+}
+int s2g_embed_grad_labels(const long long* labels, const int* lengths, int T, int B, int n_classes, const float* dx,
+                          float* dlab, int accumulate, void* stream) {
+  if (!labels || !dx || !dlab || T <= 0 || B <= 0 || n_classes <= 0) return -1;
+  hipLaunchKernelGGL(s2g_k_embed_grad_labels, dim3(n_classes), dim3(256), 0, ST(stream), labels, lengths, T, B, dx, dlab,
+                     accumulate);
+  return LAUNCH_OK();
+}
+int s2g_attnpool_fwd(float* pre, const float* out, const float* wc, const float* wl, const float* bl, int nseq, int T,
+                     int Tp, float* weights, float* pooled, float* dval, void* stream) {
+  if (!pre || !out || !wc || !wl || !bl || !weights || !pooled || !dval || nseq <= 0 || T <= 0 || Tp <= 0 || Tp > T ||
+      Tp > 12288)
+    return -1;
+  hipLaunchKernelGGL(s2g_k_attnpool_fwd, dim3(nseq), dim3(256), (size_t)Tp * sizeof(float), ST(stream), pre, out, wc, wl,
+                     bl, T, Tp, weights, pooled, dval);
+  return LAUNCH_OK();
+}
+int s2g_attnpool_bwd(float* a_dpre, const float* out, const float* wc, const float* wl, const float* weights,
+                     const float* dD, int nseq, int T, int Tp, float* dout, float* dwc_part, void* stream) {
+  if (!a_dpre || !out || !wc || !wl || !weights || !dD || !dout || !dwc_part || nseq <= 0 || T <= 0 || Tp <= 0 ||
+      Tp > T || Tp > 12288)
+    return -1;
+  hipLaunchKernelGGL(s2g_k_attnpool_bwd, dim3(nseq), dim3(256), (size_t)Tp * sizeof(float), ST(stream), a_dpre, out, wc,
+                     wl, weights, dD, T, Tp, dout, dwc_part);
+  return LAUNCH_OK();
+}
+int s2g_wasserstein_loss(const float* dval, int B, float* dD, float* loss, void* stream) {
+  if (!dval || !dD || !loss || B <= 0) return -1;
+  hipLaunchKernelGGL(s2g_k_wasserstein_loss, dim3(1), dim3(256), 0, ST(stream), dval, B, dD, loss);
+  return LAUNCH_OK();
+}
+int s2g_clamp(float* p, long n, float clip, void* stream) {
+  if (!p || n <= 0 || !(clip >= 0.0f)) return -1;
+  hipLaunchKernelGGL(s2g_k_clamp, dim3(cdiv(n, 256)), dim3(256), 0, ST(stream), p, n, clip);
+  return LAUNCH_OK();
+}
+int s2g_mul_inplace(float* a, const float* b, long n, void* stream) {
+  if (!a || !b || n <= 0) return -1;
+  hipLaunchKernelGGL(s2g_k_mul_inplace, dim3(cdiv(n, 256)), dim3(256), 0, ST(stream), a, b, n);
   return LAUNCH_OK();
 }
 

@@ -55,7 +55,7 @@ SIGNATURES = {
     "s2g_gumbel_softmax_fwd": [P, P, P, I, P, P, L, I, F, I, I, P],
     "s2g_gumbel_softmax_fwd_rng": [P, P, I, P, P, L, I, F, I, U64, U64, P],
     "s2g_rng_fill": [P, L, I, U64, U64, P],
-    "s2g_dropout_mask_rng": [P, L, F, U64, U64, P],
+    "s2g_dropout_mask_rng": [P, L, I, I, F, U64, U64, P],
     "s2g_gumbel_softmax_bwd": [P, P, P, L, I, F, P],
     "s2g_argmax_rows": [P, P, L, I, P],
     "s2g_gemm_f32": [ctypes.POINTER(S2GGemm), I, P],
@@ -102,6 +102,16 @@ SIGNATURES = {
     "s2g_bn_lrelu_fwd_fused": [P, P, P, P, P, F, F, I, P, P, P, I, I, P],
     "s2g_bn_lrelu_bwd_fused": [P, P, P, P, P, P, P, P, I, I, P],
     "s2g_adam": [P, P, P, P, L, F, F, F, F, I, F, P],
+    "s2g_lstm64_fwd": [P, P, P, I, I, P, P, P, P, P, P],
+    "s2g_lstm64_bwd": [P, P, P, I, I, P, P, P, P],
+    "s2g_embed_concat": [P, P, I, P, P, I, I, L, I, P, P],
+    "s2g_embed_grad_tokens": [P, P, I, L, I, P, P, I, P],
+    "s2g_embed_grad_labels": [P, P, I, I, I, P, P, I, P],
+    "s2g_attnpool_fwd": [P, P, P, P, P, I, I, I, P, P, P, P],
+    "s2g_attnpool_bwd": [P, P, P, P, P, P, I, I, I, P, P, P],
+    "s2g_wasserstein_loss": [P, I, P, P, P],
+    "s2g_clamp": [P, L, F, P],
+    "s2g_mul_inplace": [P, P, L, P],
     "s2g_attention_fwd": [P, P, P, P, P, P, P, ctypes.POINTER(S2GAttn), P],
     "s2g_attention_bwd": [P, P, P, P, P, P, P, P, P, P, P, ctypes.POINTER(S2GAttn), P],
     "s2g_stream_create_cu_mask": [P, I, P],

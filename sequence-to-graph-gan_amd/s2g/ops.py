@@ -185,11 +185,12 @@ def rng_fill(out: torch.Tensor, kind: int, rng: DeviceRng) -> torch.Tensor:
     return out
 
 
-def dropout_mask_rng(rows: int, p: float, device, rng: DeviceRng) -> torch.Tensor:
-    """[rows, 52] multipliers (0 or 1/(1-p); columns 50, 51 zero) of the critic's inter-layer dropout."""
-    m = torch.empty(rows, MASKW, device=device)
+def dropout_mask_rng(rows: int, p: float, device, rng: DeviceRng, width: int = MASKW, live: int = H) -> torch.Tensor:
+    """[rows, width] multipliers (0 or 1/(1-p); columns >= live zero) of an LSTM's inter-layer dropout
+    (default: the H = 50 critic's rows padded to 52)."""
+    m = torch.empty(rows, width, device=device)
     seed, off = rng.take()
-    call("s2g_dropout_mask_rng", ptr(m), rows, float(p), seed, off, stream_ptr())
+    call("s2g_dropout_mask_rng", ptr(m), rows, width, live, float(p), seed, off, stream_ptr())
     return m
 
 

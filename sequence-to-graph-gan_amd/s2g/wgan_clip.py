@@ -1,0 +1,250 @@
+"""Host orchestration of the weight-clipping WGAN variant (reference wgan.py): the LSTM generator's forward
+(:46-71), the LSTM + attention-pooling critic's forward and hand-derived backward (:92-122), and the critic
+update of CWGAN.train_step (:174-198: Wasserstein loss, Adam, weight clipping).  Every product is a libs2g
+kernel; one LSTM layer = one batched input product + one sweep over time; weight gradients are batched
+products over the saved gate gradients."""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+from .critic import FlatBuffer
+from .lib import S2GError, call
+from .ops import ptr, stream_ptr
+
+HID, G4X, EMB = 64, 256, 32
+LATENT_LEN = 100          # Generator.seq_len = latent_dim = 100 (wgan.py:52-53)
+
+
+def _lstm_shapes(prefix: str, layers: int):
+    out = []
+    for l in range(layers):
+        out += [(f"{prefix}.weight_ih_l{l}", (G4X, HID)), (f"{prefix}.weight_hh_l{l}", (G4X, HID)),
+                (f"{prefix}.bias_ih_l{l}", (G4X,)), (f"{prefix}.bias_hh_l{l}", (G4X,))]
+    return out
+
+
+def critic_shapes(vocab: int, layers: int, n_classes: int = 2):
+    """state_dict order of the reference Discriminator (wgan.py:93-103)."""
+    return ([("label_embedding.weight", (n_classes, EMB)), ("sequence_embedding.embed_layer.weight", (vocab, EMB))]
+            + _lstm_shapes("lstm", layers)
+            + [("attention.attn.weight", (HID, HID)), ("attention.attn.bias", (HID,)),
+               ("attention.context_vector.weight", (1, HID)), ("linear.weight", (1, HID)), ("linear.bias", (1,))])
+
+
+def generator_shapes(vocab: int, layers: int, n_classes: int = 2):
+    """state_dict order of the reference Generator (wgan.py:47-61)."""
+    return ([("label_embedding.weight", (n_classes, EMB)), ("noise_embedding.weight", (vocab, EMB))]
+            + _lstm_shapes("lstm", layers) + [("linear.weight", (vocab, HID)), ("linear.bias", (vocab,))])
+
+
+def _tn(A: int, lda: int, M: int, B: int, ldb: int, N: int, K: int, out: torch.Tensor, scratch: ops.Scratch,
+        accumulate: bool, segT: int = 0, shift: bool = False) -> None:
+    """out[M, N] (+)= sum_k A[k][m] B[k][n] over K rows (A, B row-major with row strides lda, ldb); with
+    shift, B's row k - 1 is used and the first row of every segment of segT rows contributes nothing."""
+    ns = ops.pick_split(M, N, K)
+    if ns == 1:
+        ops.gemm_raw(A, 1, lda, B, ldb, 1, ptr(out), N, M, N, K, accumulate=accumulate, segT=segT, a_seg=segT,
+                     b_seg=segT, shift=shift)
+    else:
+        slabs = scratch.get(ns * M * N)
+        ops.gemm_raw(A, 1, lda, B, ldb, 1, ptr(slabs), N, M, N, K, nsplit=ns, slab=M * N, segT=segT, a_seg=segT,
+                     b_seg=segT, shift=shift)
+        ops.reduce_slabs(slabs, M * N, ns, M, N, out, accumulate=accumulate)
+
+
+class _LstmStack:
+    """Shared by both networks: the layers of an nn.LSTM(64, 64, layers, batch_first=True)."""
+
+    def __init__(self, params: FlatBuffer, layers: int, device):
+        self.p, self.layers, self.device = params, layers, device
+        self.bsum = [torch.empty(G4X, device=device) for _ in range(layers)]
+
+    def forward(self, x: torch.Tensor, B: int, T: int, lengths: Optional[torch.Tensor],
+                masks: Optional[List[Optional[torch.Tensor]]], save: bool):
+        p, dev, rows = self.p.views, self.device, B * T
+        inp, saved = x, []
+        for l in range(self.layers):
+            # b_ih + b_hh (adjacent views of the flat buffer) -> one bias for the batched input product
+            ops.reduce_slabs(p[f"lstm.bias_ih_l{l}"], G4X, 2, 1, G4X, self.bsum[l])
+            pin = torch.empty(rows, G4X, device=dev)
+            ops.linear_fwd(inp, p[f"lstm.weight_ih_l{l}"], self.bsum[l], pin)
+            gates, cst, hout = (torch.empty(rows, G4X, device=dev), torch.empty(rows, HID, device=dev),
+                                torch.empty(rows, HID, device=dev))
+            mask = masks[l] if (masks is not None and l + 1 < self.layers) else None
+            hdrop = torch.empty(rows, HID, device=dev) if mask is not None else None
+            call("s2g_lstm64_fwd", ptr(pin), ptr(p[f"lstm.weight_hh_l{l}"]), ptr(lengths), B, T, ptr(gates), ptr(cst),
+                 ptr(hout), ptr(mask), ptr(hdrop), stream_ptr())
+            if save:
+                saved.append(dict(inp=inp, gates=gates, cst=cst, hout=hout, mask=mask))
+            inp = hdrop if hdrop is not None else hout
+        return hout, saved
+
+    def backward(self, dh: torch.Tensor, saved, B: int, T: int, lengths: Optional[torch.Tensor], g: Dict[str, torch.Tensor],
+                 scratch: ops.Scratch, accumulate: bool) -> torch.Tensor:
+        """dh [rows, 64]: gradient of the top layer's outputs.  Accumulates the LSTM parameter gradients into g
+        and returns the gradient of the stack's input [rows, 64]."""
+        p, dev, rows = self.p.views, self.device, B * T
+        for l in reversed(range(self.layers)):
+            s = saved[l]
+            delta = torch.empty(rows, G4X, device=dev)
+            call("s2g_lstm64_bwd", ptr(dh), ptr(p[f"lstm.weight_hh_l{l}"]), ptr(lengths), B, T, ptr(s["gates"]),
+                 ptr(s["cst"]), ptr(delta), stream_ptr())
+            _tn(ptr(delta), G4X, G4X, ptr(s["inp"]), HID, HID, rows, g[f"lstm.weight_ih_l{l}"], scratch, accumulate)
+            _tn(ptr(delta), G4X, G4X, ptr(s["hout"]), HID, HID, rows, g[f"lstm.weight_hh_l{l}"], scratch, accumulate,
+                segT=T, shift=True)
+            ops.colsum(delta, rows, G4X, G4X, g[f"lstm.bias_ih_l{l}"], scratch, accumulate=accumulate)
+            dinp = torch.empty(rows, HID, device=dev)
+            ops.linear_bwd_dx(delta, p[f"lstm.weight_ih_l{l}"], dinp, scratch)
+            if l > 0 and saved[l - 1]["mask"] is not None:
+                call("s2g_mul_inplace", ptr(dinp), ptr(saved[l - 1]["mask"]), dinp.numel(), stream_ptr())
+            dh = dinp
+        return dh
+
+
+class ClipGeneratorEngine:
+    """Generator.forward of wgan.py:63-71 (forward only: the critic update detaches its output, :185)."""
+
+    def __init__(self, vocab: int, layers: int, device, n_classes: int = 2):
+        self.V, self.layers, self.n_classes, self.device = vocab, layers, n_classes, device
+        self.params = FlatBuffer(generator_shapes(vocab, layers, n_classes), device)
+        self.stack = _LstmStack(self.params, layers, device)
+        self.rng = ops.DeviceRng()
+
+    def load(self, state: Dict[str, torch.Tensor]) -> None:
+        for k, v in self.params.views.items():
+            v.copy_(state[k].to(self.device, torch.float32))
+
+    def forward(self, noise: torch.Tensor, labels: torch.Tensor, tau: float, U: Optional[torch.Tensor] = None,
+                act: str = "gumbel_softmax", hard: bool = False) -> torch.Tensor:
+        """noise int32 [B, 100] token ids (torch.randint(0, V, ...), wgan.py:183), labels int64 [B] -> [B, 100, V]."""
+        ops._chk(noise, torch.int32, "noise"); ops._chk(labels, torch.int64, "labels")
+        B, T = noise.shape
+        p, dev = self.params.views, self.device
+        x = torch.empty(B * T, 2 * EMB, device=dev)
+        call("s2g_embed_concat", ptr(noise), ptr(p["noise_embedding.weight"]), self.V, ptr(labels),
+             ptr(p["label_embedding.weight"]), self.n_classes, T, B * T, 0, ptr(x), stream_ptr())
+        hout, _ = self.stack.forward(x, B, T, None, None, save=False)
+        logits = torch.empty(B * T, self.V, device=dev)
+        ops.linear_fwd(hout, p["linear.weight"], p["linear.bias"], logits)
+        mode = ops.MODES.get(act, 2)
+        y, _ = ops.gumbel_softmax_fwd(logits.view(B, T, self.V), U if mode == 0 else None, tau, mode, hard, rng=self.rng)
+        return y
+
+
+class ClipCriticEngine:
+    """Discriminator of wgan.py:92-122 with its backward, and the critic update of CWGAN.train_step (:174-198)."""
+
+    def __init__(self, vocab: int, layers: int, device, dropout: float = 0.1, n_classes: int = 2):
+        self.V, self.layers, self.n_classes, self.device, self.dropout = vocab, layers, n_classes, device, dropout
+        self.params = FlatBuffer(critic_shapes(vocab, layers, n_classes), device)
+        self.grads = self.params.like()
+        self.m, self.v = self.params.like(), self.params.like()
+        self.step = 0
+        self.stack = _LstmStack(self.params, layers, device)
+        self.scratch = ops.Scratch(device)
+        self.rng = ops.DeviceRng()
+
+    def load(self, state: Dict[str, torch.Tensor]) -> None:
+        for k, v in self.params.views.items():
+            v.copy_(state[k].to(self.device, torch.float32))
+
+    # ------------------------------------------------------------------ one pass (real tokens or soft fakes)
+    def forward(self, seq: torch.Tensor, labels: torch.Tensor, lengths: Optional[torch.Tensor], Tp: int,
+                masks=None, dval: Optional[torch.Tensor] = None, save: bool = True):
+        """seq: int32 [B, T] tokens (the lookup branch of RelaxedEmbedding) or fp32 [B, T, V] (the matmul branch);
+        lengths int32 [B] on the device or None (all T); Tp = the longest length (pad_packed_sequence's width).
+        Returns (D values [B], saved state)."""
+        p, dev = self.params.views, self.device
+        soft = seq.dtype != torch.int32
+        B, T = seq.shape[0], seq.shape[1]
+        rows = B * T
+        if not 1 <= Tp <= T:
+            raise S2GError("critic: the longest length must lie in [1, T]")
+        x = torch.empty(rows, 2 * EMB, device=dev)
+        if soft:
+            ops._chk(seq, name="sequence")
+            ops.gemm_raw(ptr(seq), self.V, 1, ptr(p["sequence_embedding.embed_layer.weight"]), EMB, 1, ptr(x), 2 * EMB,
+                         rows, EMB, self.V)
+        call("s2g_embed_concat", None if soft else ptr(seq), ptr(p["sequence_embedding.embed_layer.weight"]), self.V,
+             ptr(labels), ptr(p["label_embedding.weight"]), self.n_classes, T, rows, int(soft), ptr(x), stream_ptr())
+        out, saved = self.stack.forward(x, B, T, lengths, masks, save)
+        pre = torch.empty(rows, HID, device=dev)
+        ops.linear_fwd(out, p["attention.attn.weight"], p["attention.attn.bias"], pre)
+        weights, pooled = torch.empty(B, T, device=dev), torch.empty(B, HID, device=dev)
+        if dval is None:
+            dval = torch.empty(B, device=dev)
+        call("s2g_attnpool_fwd", ptr(pre), ptr(out), ptr(p["attention.context_vector.weight"]), ptr(p["linear.weight"]),
+             ptr(p["linear.bias"]), B, T, Tp, ptr(weights), ptr(pooled), ptr(dval), stream_ptr())
+        state = dict(seq=seq, soft=soft, labels=labels, lengths=lengths, B=B, T=T, Tp=Tp, x=x, out=out, a=pre,
+                     weights=weights, pooled=pooled, lstm=saved) if save else None
+        return dval, state
+
+    def backward(self, st, dD: torch.Tensor, accumulate: bool) -> None:
+        """Adds (or writes, accumulate=False) the parameter gradients of sum_n dD[n] * D_n into self.grads."""
+        p, g, dev, sc = self.params.views, self.grads.views, self.device, self.scratch
+        B, T, Tp, rows = st["B"], st["T"], st["Tp"], st["B"] * st["T"]
+        dout = torch.empty(rows, HID, device=dev)
+        dwc = torch.empty(B, HID, device=dev)
+        call("s2g_attnpool_bwd", ptr(st["a"]), ptr(st["out"]), ptr(p["attention.context_vector.weight"]),
+             ptr(p["linear.weight"]), ptr(st["weights"]), ptr(dD), B, T, Tp, ptr(dout), ptr(dwc), stream_ptr())
+        dpre = st["a"]
+        ops.colsum(dwc, B, HID, HID, g["attention.context_vector.weight"], sc, accumulate=accumulate)
+        _tn(ptr(dD), 1, 1, ptr(st["pooled"]), HID, HID, B, g["linear.weight"], sc, accumulate)
+        ops.colsum(dD, B, 1, 1, g["linear.bias"], sc, accumulate=accumulate)
+        _tn(ptr(dpre), HID, HID, ptr(st["out"]), HID, HID, rows, g["attention.attn.weight"], sc, accumulate)
+        ops.colsum(dpre, rows, HID, HID, g["attention.attn.bias"], sc, accumulate=accumulate)
+        # d(out) += d(pre) Wa
+        ops.gemm_raw(ptr(dpre), HID, 1, ptr(p["attention.attn.weight"]), HID, 1, ptr(dout), HID, rows, HID, HID,
+                     accumulate=True)
+        dx = self.stack.backward(dout, st["lstm"], B, T, st["lengths"], g, sc, accumulate)
+        ge = g["sequence_embedding.embed_layer.weight"]
+        if st["soft"]:
+            _tn(ptr(st["seq"]), self.V, self.V, ptr(dx), 2 * EMB, EMB, rows, ge, sc, accumulate)
+        else:
+            lens = st["lengths"]
+            if lens is None:
+                lens = torch.full((B,), T, dtype=torch.int32, device=dev)
+            call("s2g_embed_grad_tokens", ptr(st["seq"]), ptr(lens), T, rows, self.V, ptr(dx), ptr(ge), int(accumulate),
+                 stream_ptr())
+        call("s2g_embed_grad_labels", ptr(st["labels"]), ptr(st["lengths"]), T, B, self.n_classes, ptr(dx),
+             ptr(g["label_embedding.weight"]), int(accumulate), stream_ptr())
+
+    def dropout_masks(self, rows: int):
+        if self.dropout <= 0.0:
+            return None
+        return [ops.dropout_mask_rng(rows, self.dropout, self.device, self.rng, width=HID, live=HID)
+                for _ in range(self.layers - 1)] + [None]
+
+    # ------------------------------------------------------------------ the critic update
+    def critic_step(self, real: torch.Tensor, labels: torch.Tensor, lengths: torch.Tensor, Tp: int, fake: torch.Tensor,
+                    lr: float, b1: float, b2: float, clip: float, masks_real="draw", masks_fake="draw",
+                    eps: float = 1e-8, update: bool = True) -> torch.Tensor:
+        """wgan.py:174-198 for one batch: D(real tokens), D(fake soft sequences of length 100), d_loss =
+        -(mean D(real) - mean D(fake)), Adam, clamp to [-clip, clip].  Returns d_loss (1-element device tensor);
+        self.grads holds the gradients.  masks_*: lists of [rows, 64] dropout multipliers per layer gap,
+        None (no dropout) or "draw" (device draws at self.dropout)."""
+        B = real.shape[0]
+        dev = self.device
+        if masks_real == "draw":
+            masks_real = self.dropout_masks(B * real.shape[1])
+        if masks_fake == "draw":
+            masks_fake = self.dropout_masks(B * fake.shape[1])
+        dval = torch.empty(2 * B, device=dev)
+        _, s_real = self.forward(real, labels, lengths, Tp, masks_real, dval[:B])
+        _, s_fake = self.forward(fake, labels, None, fake.shape[1], masks_fake, dval[B:])
+        dD, loss = torch.empty(2 * B, device=dev), torch.empty(1, device=dev)
+        call("s2g_wasserstein_loss", ptr(dval), B, ptr(dD), ptr(loss), stream_ptr())
+        self.backward(s_real, dD[:B], accumulate=False)
+        self.backward(s_fake, dD[B:], accumulate=True)
+        g = self.grads.views
+        for l in range(self.layers):                    # b_ih and b_hh enter the gates as a sum: one gradient
+            g[f"lstm.bias_hh_l{l}"].copy_(g[f"lstm.bias_ih_l{l}"])
+        if update:
+            self.step += 1
+            ops.adam(self.params.flat, self.grads.flat, self.m.flat, self.v.flat, lr, b1, b2, eps, self.step)
+            call("s2g_clamp", ptr(self.params.flat), self.params.total, float(clip), stream_ptr())
+        self.last_values = dval
+        return loss

@@ -481,6 +481,49 @@ def g11_attention(ref):
     save("g11_attention.pt", out)
 
 
+def g12_wgan_clip(ref):
+    """The critic update of the reference's weight-clipping WGAN (wgan.py:174-198) through its own classes:
+    CWGAN.train_step over a ONE-batch loader (i = 0: the generator branch, which would raise AttributeError on
+    the undefined self.loss, wgan.py:214, is skipped by the inverted test `if i % n_critic`, :206), three
+    calls in a row on different batches.  Records d_loss per call (train_step returns it), the critic's
+    gradients at every update and its parameters after the three clamped Adam steps."""
+    sys.modules.setdefault("seaborn", types.ModuleType("seaborn"))
+    import wgan as W                                  # /root/reference/wgan.py
+    assert W.__file__.startswith("/root/reference")
+    V, B, T = 175, 6, 40
+    pd, pg = common.wgan_clip_params(1401, V)
+    opt = argparse.Namespace(lr=2e-4, beta1=0.5, beta2=0.999, clip_value=0.1, n_critic=5)
+    G = W.Generator(V, 2, 3, softmax="gumbel_softmax")
+    D = W.Discriminator(V, 2, 2, dropout=0.0, use_gpu=False)
+    G.load_state_dict(pg); D.load_state_dict(pd)
+    model = W.CWGAN(G, D, opt)
+    snaps = []
+    model.d_optimizer.register_step_pre_hook(
+        lambda o, a, k: snaps.append({n: q.grad.detach().clone() for n, q in D.named_parameters()}))
+    out = {}
+    real_randint = torch.randint
+    for it in range(3):
+        tokens, labels, lengths = common.batch(1410 + it, B, T, vocab=V, min_len=4)
+        g = common.gen(1420 + it)
+        noise = real_randint(0, V, (B, 100), generator=g)
+        U = torch.rand((B, 100, V), generator=g)
+        qU = Queue(); qU.push(U)
+        torch.randint = lambda *a, **k: noise.clone()             # wgan.py:183
+        try:
+            import contextlib, io
+            with injected(ref, qU, Queue(), Queue()), contextlib.redirect_stderr(io.StringIO()):
+                d_loss, _ = model.train_step(ListLoader([(tokens, labels, lengths)]), 0.5, False)
+        finally:
+            torch.randint = real_randint
+        out[f"d_loss{it}"] = torch.tensor(d_loss, dtype=torch.float64)
+        for n, v in snaps[it].items():
+            out[f"grad{it}.{n}"] = v
+    for n, v in D.state_dict().items():
+        out[f"D.{n}"] = v.clone()
+    print("g12: d_loss", [float(out[f"d_loss{i}"]) for i in range(3)])
+    save("g12_wgan_clip.pt", out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
@@ -488,7 +531,7 @@ def main():
     a = ap.parse_args()
     torch.manual_seed(0)
     ref = import_reference()
-    todo = [g1_sampler, g2_generator, g3_critic, g4_gp, g5_ce, g6_adam, g7_full_step, g10_generate_fake_data, g11_attention]
+    todo = [g1_sampler, g2_generator, g3_critic, g4_gp, g5_ce, g6_adam, g7_full_step, g10_generate_fake_data, g11_attention, g12_wgan_clip]
     if a.full:
         todo += [g8_full_size, g9_full_step_full_size]
     for fn in todo:

@@ -1,0 +1,119 @@
+"""The weight-clipping WGAN variant (reference wgan.py) on the HIP kernels: three critic updates
+(CWGAN.train_step lines 174-198: D(real tokens), G(noise).detach(), D(fake), Wasserstein loss, Adam, clamp)
+against what the reference's own classes produced (g12), and a larger ragged batch with inter-layer dropout
+masks against the CPU restatement.  1e-3 relative, the fp32 bound."""
+import pytest
+import torch
+
+import common
+from conftest import assert_close, assert_update_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-3
+
+
+def engines(seed, V=175, dropout=0.0):
+    from s2g.wgan_clip import ClipCriticEngine, ClipGeneratorEngine
+    pd, pg = common.wgan_clip_params(seed, V)
+    D = ClipCriticEngine(V, 2, torch.device(DEV), dropout=dropout)
+    G = ClipGeneratorEngine(V, 3, torch.device(DEV))
+    D.load(pd); G.load(pg)
+    return D, G, pd, pg
+
+
+def test_three_critic_updates_match_reference_golden(golden):
+    Gd = golden("g12_wgan_clip.pt")
+    V, B, T = 175, 6, 40
+    D, G, pd, _ = engines(1401, V)
+    for it in range(3):
+        tokens, labels, lengths = common.batch(1410 + it, B, T, vocab=V, min_len=4)
+        g = common.gen(1420 + it)
+        noise = torch.randint(0, V, (B, 100), generator=g)
+        U = torch.rand((B, 100, V), generator=g)
+        fake = G.forward(noise.to(torch.int32).to(DEV), labels.to(DEV), 0.5, U=U.to(DEV))
+        loss = D.critic_step(tokens.to(torch.int32).to(DEV).contiguous(), labels.to(DEV), lengths.to(torch.int32).to(DEV),
+                             int(lengths.max()), fake, 2e-4, 0.5, 0.999, 0.1, masks_real=None, masks_fake=None)
+        torch.cuda.synchronize()
+        assert abs(float(loss) - float(Gd[f"d_loss{it}"])) < TOL * max(1.0, abs(float(Gd[f"d_loss{it}"])))
+        for n, gv in D.grads.views.items():
+            assert_close(gv, Gd[f"grad{it}.{n}"], TOL, f"grad{it} {n}", atol=1e-9)
+    for n, v in D.params.views.items():
+        assert_close(v, Gd[f"D.{n}"], TOL, n)
+        if n != "linear.bias":          # d(loss)/d(linear.bias) = -1 + 1 = 0: the reference never moves it
+            assert_update_close(v, pd[n], Gd[f"D.{n}"], TOL, n)
+        assert float(v.abs().max()) <= 0.1 + 1e-7
+
+
+def test_ragged_batch_with_dropout_masks_matches_oracle():
+    from oracle import wgan_clip_cpu as O
+    V, B, T = 175, 16, 96
+    D, G, pd, pg = engines(1501, V, dropout=0.3)
+    tokens, labels, lengths = common.batch(1510, B, T, vocab=V, min_len=2)
+    lengths[0] = 70                                            # the longest sequence is shorter than the padded width
+    lengths = torch.sort(lengths.clamp(max=70), descending=True).values
+    g = common.gen(1520)
+    noise = torch.randint(0, V, (B, 100), generator=g)
+    U = torch.rand((B, 100, V), generator=g)
+    m_real = (torch.rand((B, T, 64), generator=g) > 0.3).float() / 0.7
+    m_fake = (torch.rand((B, 100, 64), generator=g) > 0.3).float() / 0.7
+    pd_o = {k: v.clone() for k, v in pd.items()}
+    opt = O.Adam(pd_o, 2e-4, 0.5, 0.999)
+    d_ref, g_ref = O.critic_step(pd_o, opt, pg, tokens, labels, lengths, noise, U, 0.5, 0.1,
+                                 masks_real=[m_real, None], masks_fake=[m_fake, None])
+    fake = G.forward(noise.to(torch.int32).to(DEV), labels.to(DEV), 0.5, U=U.to(DEV))
+    fake_ref = O.generator_forward(pg, noise, labels, U, 0.5)
+    assert_close(fake, fake_ref, TOL, "generator sample")
+    loss = D.critic_step(tokens.to(torch.int32).to(DEV).contiguous(), labels.to(DEV), lengths.to(torch.int32).to(DEV),
+                         int(lengths.max()), fake, 2e-4, 0.5, 0.999, 0.1,
+                         masks_real=[m_real.reshape(B * T, 64).to(DEV), None],
+                         masks_fake=[m_fake.reshape(B * 100, 64).to(DEV), None])
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(d_ref)) < TOL * max(1.0, abs(float(d_ref)))
+    for n, gv in D.grads.views.items():
+        assert_close(gv, g_ref[n], TOL, f"grad {n}", atol=1e-9)
+    for n, v in D.params.views.items():
+        assert_close(v, pd_o[n], TOL, n)
+
+
+def test_device_dropout_masks_have_the_right_rate():
+    D, _, _, _ = engines(1601, dropout=0.3)
+    m = D.dropout_masks(4096)
+    torch.cuda.synchronize()
+    assert m[-1] is None and tuple(m[0].shape) == (4096, 64)
+    keep = (m[0] != 0).float().mean().item()
+    assert abs(keep - 0.7) < 0.01 and abs(float(m[0].max()) - 1.0 / 0.7) < 1e-6
+
+
+def test_module_surface_and_train_step_follow_the_reference(golden):
+    """wgan.py's classes: state_dict keys of the reference, CWGAN.train_step = the reference's critic update on a
+    one-batch loader (the first d_loss of g12), and the reference's AttributeError on a second batch."""
+    import argparse
+    import wgan as W
+    Gd = golden("g12_wgan_clip.pt")
+    V, B, T = 175, 6, 40
+    pd, pg = common.wgan_clip_params(1401, V)
+    G = W.Generator(V, 2, 3, softmax="gumbel_softmax")
+    D = W.Discriminator(V, 2, 2, dropout=0.0)
+    assert set(D.state_dict()) == set(pd) and set(G.state_dict()) == set(pg)
+    G.load_state_dict(pg); D.load_state_dict(pd)
+    opt = argparse.Namespace(lr=2e-4, beta1=0.5, beta2=0.999, clip_value=0.1, n_critic=5)
+    model = W.CWGAN(G, D, opt)
+    tokens, labels, lengths = common.batch(1410, B, T, vocab=V, min_len=4)
+    g = common.gen(1420)
+    noise = torch.randint(0, V, (B, 100), generator=g)
+    U = torch.rand((B, 100, V), generator=g)
+    real_randint, real_rand = torch.randint, torch.rand
+    torch.randint = lambda *a, **k: noise.clone()
+    torch.rand = lambda *a, **k: U.clone()
+    try:
+        d_loss, g_loss = model.train_step([(tokens, labels, lengths)], 0.5, False)
+        assert abs(d_loss - float(Gd["d_loss0"])) < TOL and g_loss == 0.0
+        out = D(tokens.to(DEV), labels.to(DEV), lengths)
+        assert tuple(out.shape) == (B, 1) and torch.isfinite(out).all()
+        with pytest.raises(AttributeError, match="loss"):
+            model.train_step([(tokens, labels, lengths)] * 2, 0.5, False)
+    finally:
+        torch.randint, torch.rand = real_randint, real_rand
+    for n, v in D.state_dict().items():            # the module's parameters ARE the engine's (two updates by now)
+        assert float(v.abs().max()) <= 0.1 + 1e-7
