@@ -65,7 +65,19 @@ def cpu_baseline(seconds_budget: float = 60.0):
         O.critic_iteration(pg, bn, pd, opt, tokens, labels, lengths, nz["z"], nz["U"], nz["alpha"], cfg)
         n += 1
     dt = time.perf_counter() - t0
+    # what the imported reference itself needed in the build container (recorded with the golden vectors)
+    ref_rec = None
+    try:
+        g8 = torch.load(os.path.join(ROOT, "tests", "golden", "g8_full_size.pt"), weights_only=True)
+        secs = float(g8["fixed.seconds"])
+        ref_rec = {"sequences_per_s": B_PER_GPU / secs, "seconds": secs,
+                   "what": "the reference's own train_wgan (imported unmodified, CPU, 8 threads of the build container): one "
+                           "critic iteration + the generator update at B=64, L=512, generator seq_len 512, no dropout; "
+                           "recorded with tests/golden/g8_full_size.pt"}
+    except Exception:
+        pass
     return {"value": n * B_PER_GPU / dt, "unit": "sequences/s", "cores": threads, "kind": "port",
+            "reference_recorded": ref_rec,
             "sample": f"{n} critic iterations (B=64, L=512, V=175, gen seq_len 512, no dropout) in {dt:.1f} s; "
                       f"host has {os.cpu_count()} logical CPUs, torch used {threads} threads"}
 
@@ -193,6 +205,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--lengths", default="fixed", choices=["fixed", "adfa"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-wgan", action="store_true", help="skip the train_wgan() path measurement (profiling runs)")
     ap.add_argument("--drop-rate", type=float, default=0.3)
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="f32 (default, the headline): exact-fp32 MFMA everywhere; bf16: bf16 operands / fp32 accumulation "
@@ -345,6 +358,20 @@ def main():
                 t = json.load(f).get(dom)
             if t:
                 traffic, traffic_src = t["bytes_per_launch"], t["source"]
+        # the HBM-bound kernels of the step (sampler, penalty pieces, one-hot / interpolation operands, Adam, draws):
+        # bytes per launch from the committed PMC passes, durations from the committed kernel-trace run of this
+        # same command (profiles/), not from this run
+        hbm_kernels = {}
+        if os.path.exists(pmc):
+            with open(pmc) as f:
+                table = json.load(f)
+            for name in ("s2g_k_gumbel_softmax_fwd_v4<true>", "s2g_k_gumbel_softmax_fwd_v4<false>", "s2g_k_gumbel_softmax_bwd_v4",
+                         "s2g_k_gp_interp", "s2g_k_one_hot", "s2g_k_gp_norm_penalty", "s2g_k_gp_dots", "s2g_k_adam",
+                         "s2g_k_dropout_mask_rng", "s2g_k_linear_wstream"):
+                t = table.get(name)
+                if t and "avg_ns" in t:
+                    hbm_kernels[name] = {"bytes_per_launch": t["bytes_per_launch"], "avg_us": t["avg_ns"] / 1e3,
+                                         "gb_per_s": t["gb_per_s"], "frac_of_hbm_peak": t["frac_of_8_tb_s"]}
         line = {
             "metric": "WGAN-GP train sequences/sec at V=175 L=512", "value": seqs / dt, "unit": "sequences/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
@@ -366,9 +393,11 @@ def main():
                                  "dependent steps (one workgroup per sequence) and are bounded by per-step latency, "
                                  "not by the FLOP or HBM roof"},
             "kernels": kernels, "launch_avg_ms": launches,
+            "hbm_bound_kernels": {"source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes and a "
+                                            "--kernel-trace --stats run of this command; peak 8000 GB/s)", **hbm_kernels},
             "second_stream": ("cu-masked, 3/4 of the CUs" if tr.D._side else None),
         }
-        if world == 1:
+        if world == 1 and not a.no_train_wgan:
             # the drop-in path (python3 wgan_gp.py ..., README.md:83): same step through train_wgan() and the nn.Module
             # surface, batches arriving from a CPU loader; with device-side draws, and with the reference-compatible
             # draws on the CPU generator (z, Gumbel uniforms, alpha: 2 x 23 MB of torch.rand + copies per batch)

@@ -3,7 +3,10 @@
 each with --kernel-trace --output-format csv) into profiles/pmc_traffic.json: HBM bytes per launch of
 every libs2g kernel.
 
-    python tools/pmc_traffic.py <fetch_dir> <write_dir> <tag>
+    python tools/pmc_traffic.py <fetch_dir> <write_dir> <tag> [<kernel_stats.csv of a --kernel-trace --stats run>]
+
+With the stats file, every kernel also gets its average duration from that (un-instrumented) run and the
+HBM rate bytes / duration (counter passes serialise the kernels, so their own timings are not used).
 
 FETCH_SIZE / WRITE_SIZE are reported in KiB.  On gfx950 FETCH_SIZE counts 64 B per 128-B read request,
 i.e. half the bytes of coalesced wide reads, so it is doubled; WRITE_SIZE is taken as is.  Check of the
@@ -31,6 +34,10 @@ def per_kernel(d, counter):
 
 def main():
     fetch_dir, write_dir, tag = sys.argv[1:4]
+    durations = {}
+    if len(sys.argv) > 4:
+        for r in csv.DictReader(open(sys.argv[4])):
+            durations[r["Name"].split("(")[0].replace("void ", "").strip()] = (float(r["AverageNs"]), int(r["Calls"]))
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     (fe, nfe), (wr, nwr) = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
     # per-kernel summaries of the two passes (the raw per-dispatch CSVs are ~0.5 MB each)
@@ -44,7 +51,11 @@ def main():
         if not k.startswith("s2g_k_"):
             continue
         rd, w = 2.0 * fe.get(k, 0.0) * 1024.0, wr.get(k, 0.0) * 1024.0
-        out[k] = {"bytes_per_launch": rd + w, "read_bytes": rd, "write_bytes": w,
+        extra = {}
+        if k in durations:
+            ns, calls = durations[k]
+            extra = {"avg_ns": ns, "calls_timed": calls, "gb_per_s": (rd + w) / ns, "frac_of_8_tb_s": (rd + w) / ns / 8000.0}
+        out[k] = {**extra, "bytes_per_launch": rd + w, "read_bytes": rd, "write_bytes": w,
                   "source": f"profiles/{tag}_pmc_fetch.csv + profiles/{tag}_pmc_write.csv (rocprofv3 --pmc FETCH_SIZE / "
                             "WRITE_SIZE, separate passes; FETCH_SIZE doubled per the gfx950 correction), mean over launches"}
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
