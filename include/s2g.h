@@ -352,6 +352,21 @@ int s2g_wasserstein_loss(const float* dval, int B, float* dD, float* loss, void*
 int s2g_clamp(float* p, long n, float clip, void* stream);
 int s2g_mul_inplace(float* a, const float* b, long n, void* stream);
 
+/* ---- sequence -> graph.  Node features of the transition graph of each token sequence, what
+ * GraphEncoder.encode (graph_encoder.py:57-133) computes per sequence with networkx (graph_encoder.py:86-91):
+ * one node per distinct symbol, an edge u -> v weighted by the number of times v follows u;
+ * feat [n_seq, V, 4] float64 = (katz_centrality_numpy(weight), betweenness_centrality, closeness_centrality,
+ * pagerank(weight)) at the symbol's id, zeros for absent symbols, for single-node graphs and (Katz only) for
+ * two-node graphs, as the reference assigns them.  tokens [n_seq, L] int32 symbol ids in [0, V), V <= 256,
+ * L <= 65535; lengths [n_seq] or NULL.  info [n_seq, 4] int32 = nodes, status, pagerank iterations, distinct
+ * edges; status bit 0: pagerank did not converge in 100 iterations (networkx raises
+ * PowerIterationFailedConvergence), bit 1: the Katz matrix I - 0.1 W^T is singular (numpy raises LinAlgError);
+ * the host mirror raises the same.  work: s2g_graph_features_workspace(n_seq, V) bytes of device memory for
+ * the Katz matrices that do not fit in LDS (n > ~118 at V = 175).  Returns -3 for sizes beyond these limits. */
+int s2g_graph_features(const int* tokens, const int* lengths, int n_seq, int L, int V, double* feat, int* info,
+                       double* work, long work_bytes, void* stream);
+long s2g_graph_features_workspace(int n_seq, int V);
+
 /* ---- streams.  No counterpart in the reference (its step is one serial autograd graph,
  * wgan_gp.py:297-317): the second-order sweeps of the penalty run one workgroup per sequence and
  * occupy B of the 256 CUs, so the host runs the work that does not depend on them on a second HIP

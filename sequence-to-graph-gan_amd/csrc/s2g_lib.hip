@@ -9,6 +9,7 @@
 #include "elementwise.hip"
 #include "attention.hip"
 #include "lstm64.hip"
+#include "graph.hip"
 #include <math.h>
 #include <mutex>
 
@@ -28,7 +29,7 @@ int s2g_gumbel_softmax_fwd(const float* logits, const float* U, const float* bia
   if (hard && !y_soft) return -1;
   if (bias && bias_rows <= 0) return -1;
   if (V <= 256)
-    hipLaunchKernelGGL(s2g_k_gumbel_softmax_fwd_v4<false>, dim3(cdiv(rows, 4)), dim3(256), 0, ST(stream), logits, U,
+    hipLaunchKernelGGL(s2g_k_gumbel_softmax_fwd_v4<false>, dim3(cdiv(rows, 4 * SAMPLER_ROWS)), dim3(256), 0, ST(stream), logits, U,
                        bias, bias_rows, y_out, y_soft, rows, V, 1.0f / tau, mode, hard, 0ULL, 0ULL);
   else
     hipLaunchKernelGGL(s2g_k_gumbel_softmax_fwd, dim3(cdiv(rows, 4)), dim3(256), 0, ST(stream), logits, U, bias,
@@ -42,7 +43,7 @@ int s2g_gumbel_softmax_fwd_rng(const float* logits, const float* bias, int bias_
   if (!logits || !y_out || rows <= 0 || V <= 0 || V > 256 || !(tau > 0.0f)) return -1;
   if (hard && !y_soft) return -1;
   if (bias && bias_rows <= 0) return -1;
-  hipLaunchKernelGGL(s2g_k_gumbel_softmax_fwd_v4<true>, dim3(cdiv(rows, 4)), dim3(256), 0, ST(stream), logits,
+  hipLaunchKernelGGL(s2g_k_gumbel_softmax_fwd_v4<true>, dim3(cdiv(rows, 4 * SAMPLER_ROWS)), dim3(256), 0, ST(stream), logits,
                      (const float*)nullptr, bias, bias_rows, y_out, y_soft, rows, V, 1.0f / tau, 0, hard, seed, offset);
   return LAUNCH_OK();
 }
@@ -67,7 +68,7 @@ int s2g_gumbel_softmax_bwd(const float* y_soft, const float* dy, float* dlogits,
                            void* stream) {
   if (!y_soft || !dy || !dlogits || rows <= 0 || V <= 0 || V > 64 * MAXPER) return -1;
   if (V <= 256)
-    hipLaunchKernelGGL(s2g_k_gumbel_softmax_bwd_v4, dim3(cdiv(rows, 4)), dim3(256), 0, ST(stream), y_soft, dy, dlogits,
+    hipLaunchKernelGGL(s2g_k_gumbel_softmax_bwd_v4, dim3(cdiv(rows, 4 * SAMPLER_ROWS)), dim3(256), 0, ST(stream), y_soft, dy, dlogits,
                        rows, V, scale);
   else
     hipLaunchKernelGGL(s2g_k_gumbel_softmax_bwd, dim3(cdiv(rows, 4)), dim3(256), 0, ST(stream), y_soft, dy,
@@ -394,7 +395,7 @@ int s2g_generator_loss(const float* out, const long long* labels, int B, float i
 }
 
 int s2g_one_hot(const int* tokens, const int* lengths, int T, float* x, long rows, int V, void* stream) {
-  if (!tokens || !x || rows <= 0 || V <= 0 || (lengths && T <= 0)) return -1;
+  if (!tokens || !x || rows <= 0 || V <= 0 || (lengths && T <= 0) || rows * V >= (1L << 31)) return -1;
   if (((uintptr_t)x) & 15) return -1;
   hipLaunchKernelGGL(s2g_k_one_hot, dim3(cdiv(cdiv(rows * V, 4), 256)), dim3(256), 0, ST(stream), tokens, lengths, T, x,
                      rows, V);
@@ -403,6 +404,7 @@ int s2g_one_hot(const int* tokens, const int* lengths, int T, float* x, long row
 int s2g_gp_interp(const int* tokens, const int* lengths, const float* fake, const float* alpha, int B, int T,
                   int Tf, int V, float* xhat, void* stream) {
   if (!tokens || !lengths || !fake || !alpha || !xhat || B <= 0 || T <= 0 || Tf <= 0 || V <= 0) return -1;
+  if ((long)B * T * V >= (1L << 31)) return -1;
   if ((((uintptr_t)xhat) | ((uintptr_t)fake)) & 15) return -1;
   hipLaunchKernelGGL(s2g_k_gp_interp, dim3(cdiv(cdiv((long)B * T * V, 4), 256)), dim3(256), 0, ST(stream), tokens,
                      lengths, fake, alpha, B, T, Tf, V, xhat);
@@ -509,8 +511,8 @@ int s2g_adam(float* p, const float* g, float* m, float* v, long n, float lr, flo
   const double bc2 = 1.0 - pow((double)b2, (double)step);
   const float step_size = (float)((double)lr / bc1);
   const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
-  unsigned blocks = cdiv(n, 1024);
-  if (blocks > 2048) blocks = 2048;
+  if (n >= (1L << 40)) return -1;
+  const unsigned blocks = cdiv(n, 1024);        // one 16-byte group per thread (the loop in the kernel runs once)
   hipLaunchKernelGGL(s2g_k_adam, dim3(blocks), dim3(256), 0, ST(stream), p, g, m, v, n, b1, b2, eps, step_size,
                      inv_sqrt_bc2, gscale);
   return LAUNCH_OK();
@@ -610,6 +612,39 @@ int s2g_attention_bwd(const float* Q, const float* K, const float* V, const floa
   AttnDims d;
   if (!Q || !K || !V || !P || !dO || !dS || !dQ || !dK || !dV || attn_dims(dims, &d) != 0) return -1;
   return s2g_launch_attn_bwd(Q, K, V, attn_mask, pad_mask, P, dO, dS, dQ, dK, dV, d, ST(stream));
+}
+
+// ---- sequence -> graph node features (reference graph_encoder.py:57-133)
+long s2g_graph_features_workspace(int n_seq, int V) {
+  if (n_seq <= 0 || V <= 0 || V > GR_NMAX) return -1;
+  return (long)n_seq * V * V * (long)sizeof(double);
+}
+int s2g_graph_features(const int* tokens, const int* lengths, int n_seq, int L, int V, double* feat, int* info,
+                       double* work, long work_bytes, void* stream) {
+  if (!tokens || !feat || !info || !work || n_seq <= 0 || L <= 0 || V <= 0) return -1;
+  if (V > GR_NMAX || L > 65535) return -3;                    // node bitmasks are 256 wide; counts are 16-bit
+  if (work_bytes < s2g_graph_features_workspace(n_seq, V)) return -3;
+  GraphArgs a;
+  a.tokens = tokens; a.lengths = lengths; a.L = L; a.V = V; a.feat = feat; a.info = info; a.work = work;
+  const long emax = (long)V * V < (long)L - 1 ? (long)V * V : (long)L - 1;
+  a.ecap = emax < 1 ? 1 : (int)emax;
+  a.uni_bytes = graph_uni_bytes(V, a.ecap);
+  if (a.uni_bytes < 0) return -3;                             // the sequence's edge lists do not fit in LDS
+  const int lds = graph_lds_layout(V, a.ecap, a.uni_bytes).total;
+  static std::mutex mu;
+  static int lds_set[64] = {0};
+  int dev = 0;
+  S2G_CHECK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) return -3;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (lds_set[dev] < lds) {
+      S2G_CHECK(hipFuncSetAttribute((const void*)s2g_k_graph_features, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      lds_set[dev] = lds;
+    }
+  }
+  hipLaunchKernelGGL(s2g_k_graph_features, dim3(n_seq), dim3(GR_THREADS), lds, ST(stream), a);
+  return LAUNCH_OK();
 }
 
 int s2g_stream_create_cu_mask(const unsigned* mask, int nwords, void** stream_out) {

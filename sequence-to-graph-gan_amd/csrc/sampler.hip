@@ -142,90 +142,126 @@ __device__ __forceinline__ void store4(float* p, int nv, const float v[4]) {
   }
 }
 
+// Rows per wave (all loads of a wave's rows are issued before its first reduction).  Measured at 32768 rows
+// of 175, caches cold: one row per wave 23 us, four rows per wave 30 us (fewer, longer waves hide less), so
+// the many-short-waves form stays.
+#ifndef SAMPLER_ROWS
+#define SAMPLER_ROWS 1
+#endif
+
+// lowest column holding the wave's maximum: lanes own ascending columns, so the first lane whose best value
+// equals the maximum holds it (one ballot and one cross-lane read instead of a six-step shuffle tree)
+__device__ __forceinline__ int first_best(float bv, int best, float wm) {
+  const unsigned long long m = __ballot(bv == wm);
+  const int src = m ? __builtin_ctzll(m) : 0;
+  return __shfl(best, src);
+}
+
 template <bool RNG>
 __global__ __launch_bounds__(256) void s2g_k_gumbel_softmax_fwd_v4(
     const float* __restrict__ logits, const float* __restrict__ U, const float* __restrict__ bias, int bias_rows,
     float* __restrict__ y_out, float* __restrict__ y_soft, long rows, int V, float inv_tau, int mode, int hard,
     unsigned long long seed, unsigned long long offset) {
+  constexpr int SR = SAMPLER_ROWS;
   const int lane = threadIdx.x & 63;
-  const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  const long row0 = ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * SR;
+  if (row0 >= rows) return;
   const int j0 = 4 * lane, nv = V - j0;          // nv >= 4: four live columns, 1..3: the row's tail, <= 0: none
-  const long base = row * V + j0;
-  float z[4], u[4];
-  load4(logits + base, nv, -INFINITY, z);
-  if (bias) {
-    float b[4];
-    load4(bias + (row % bias_rows) * V + j0, nv, 0.0f, b);
+  float z[SR][4], u[SR][4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) z[k] += b[k];
+  for (int r = 0; r < SR; ++r) {
+    const long row = row0 + r;
+    const int n = row < rows ? nv : 0;
+    load4(logits + row * V + j0, n, -INFINITY, z[r]);
+    if (mode == 0 && !RNG) load4(U + row * V + j0, n, 0.5f, u[r]);
   }
-  if (mode == 0) {
-    if (RNG) {
-      const Philox4 r = philox4x32_10((unsigned long long)row * 64 + lane, offset, seed);
-      u[0] = u01(r.x); u[1] = u01(r.y); u[2] = u01(r.z); u[3] = u01(r.w);
-    } else {
-      load4(U + base, nv, 0.5f, u);
+  if (bias) {
+#pragma unroll
+    for (int r = 0; r < SR; ++r) {
+      const long row = row0 + r;
+      float b[4];
+      load4(bias + (row % bias_rows) * V + j0, row < rows ? nv : 0, 0.0f, b);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) z[r][k] += b[k];
     }
+  }
+#pragma unroll
+  for (int r = 0; r < SR; ++r) {
+    const long row = row0 + r;
+    if (row >= rows) break;                        // wave-uniform
+    const long base = row * V + j0;
+    if (mode == 0) {
+      if (RNG) {
+        const Philox4 q = philox4x32_10((unsigned long long)row * 64 + lane, offset, seed);
+        u[r][0] = u01(q.x); u[r][1] = u01(q.y); u[r][2] = u01(q.z); u[r][3] = u01(q.w);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float uu = 1e-10f + (1.0f - 1e-10f) * u[r][k];
+        z[r][k] += -logf(-logf(uu + 1e-20f) + 1e-20f);
+      }
+    }
+    float mx = -INFINITY;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float uu = 1e-10f + (1.0f - 1e-10f) * u[k];
-      z[k] += -logf(-logf(uu + 1e-20f) + 1e-20f);
+      z[r][k] = k < nv ? ((mode == 2) ? z[r][k] : z[r][k] * inv_tau) : -INFINITY;
+      mx = fmaxf(mx, z[r][k]);
     }
+    mx = wave_max(mx);
+    float sum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      z[r][k] = k < nv ? expf(z[r][k] - mx) : 0.0f;
+      sum += z[r][k];
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    float pr[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pr[k] = z[r][k] * inv;
+    if (y_soft) store4(y_soft + base, nv, pr);
+    if (hard) {
+      float bv = -1.0f;
+      int best = 0x7fffffff;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (k < nv && pr[k] > bv) { bv = pr[k]; best = j0 + k; }
+      const int cand = first_best(bv, best, wave_max(bv));
+#pragma unroll
+      for (int k = 0; k < 4; ++k) pr[k] = (j0 + k == cand) ? 1.0f : 0.0f;
+    }
+    store4(y_out + base, nv, pr);
   }
-  float mx = -INFINITY;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    z[k] = k < nv ? ((mode == 2) ? z[k] : z[k] * inv_tau) : -INFINITY;
-    mx = fmaxf(mx, z[k]);
-  }
-  mx = wave_max(mx);
-  float sum = 0.0f;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    z[k] = k < nv ? expf(z[k] - mx) : 0.0f;
-    sum += z[k];
-  }
-  sum = wave_sum(sum);
-  const float inv = 1.0f / sum;
-  float pr[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) pr[k] = z[k] * inv;
-  if (y_soft) store4(y_soft + base, nv, pr);
-  if (hard) {
-    float bv = -1.0f;
-    int best = 0x7fffffff;
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (k < nv && pr[k] > bv) { bv = pr[k]; best = j0 + k; }
-    const float wm = wave_max(bv);
-    int cand = (bv == wm) ? best : 0x7fffffff;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) cand = min(cand, __shfl_xor(cand, o));
-#pragma unroll
-    for (int k = 0; k < 4; ++k) pr[k] = (j0 + k == cand) ? 1.0f : 0.0f;
-  }
-  store4(y_out + base, nv, pr);
 }
 
 extern "C" __global__ __launch_bounds__(256) void s2g_k_gumbel_softmax_bwd_v4(
     const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dlogits, long rows, int V,
     float scale) {
+  constexpr int SR = SAMPLER_ROWS;
   const int lane = threadIdx.x & 63;
-  const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  const long row0 = ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * SR;
+  if (row0 >= rows) return;
   const int j0 = 4 * lane, nv = V - j0;
-  const long base = row * V + j0;
-  float yv[4], dv[4];
-  load4(y + base, nv, 0.0f, yv);
-  load4(dy + base, nv, 0.0f, dv);
-  float dot = 0.0f;
+  float yv[SR][4], dv[SR][4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) dot = fmaf(yv[k], dv[k], dot);
-  dot = wave_sum(dot);
+  for (int r = 0; r < SR; ++r) {
+    const long row = row0 + r;
+    const int n = row < rows ? nv : 0;
+    load4(y + row * V + j0, n, 0.0f, yv[r]);
+    load4(dy + row * V + j0, n, 0.0f, dv[r]);
+  }
 #pragma unroll
-  for (int k = 0; k < 4; ++k) dv[k] = scale * yv[k] * (dv[k] - dot);
-  store4(dlogits + base, nv, dv);
+  for (int r = 0; r < SR; ++r) {
+    const long row = row0 + r;
+    if (row >= rows) break;                        // wave-uniform
+    float dot = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dot = fmaf(yv[r][k], dv[r][k], dot);
+    dot = wave_sum(dot);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dv[r][k] = scale * yv[r][k] * (dv[r][k] - dot);
+    store4(dlogits + row * V + j0, nv, dv[r]);
+  }
 }
 
 // tokens[row] = argmax_j y[row][j]  (generate_fake_data.py:66), first maximal index.

@@ -114,6 +114,8 @@ SIGNATURES = {
     "s2g_mul_inplace": [P, P, L, P],
     "s2g_attention_fwd": [P, P, P, P, P, P, P, ctypes.POINTER(S2GAttn), P],
     "s2g_attention_bwd": [P, P, P, P, P, P, P, P, P, P, P, ctypes.POINTER(S2GAttn), P],
+    "s2g_graph_features": [P, P, I, I, I, P, P, P, L, P],
+    "s2g_graph_features_workspace": [I, I],
     "s2g_stream_create_cu_mask": [P, I, P],
     "s2g_stream_destroy": [P],
 }
@@ -135,6 +137,7 @@ def load(path: str = LIB_PATH) -> ctypes.CDLL:
             raise S2GError(f"libs2g.so does not export {name}") from e
         fn.argtypes = argtypes
         fn.restype = ctypes.c_int
+    lib.s2g_graph_features_workspace.restype = ctypes.c_long      # a byte count
     return lib
 
 

@@ -524,6 +524,64 @@ def g12_wgan_clip(ref):
     save("g12_wgan_clip.pt", out)
 
 
+def g13_graph_encoder(ref):
+    """GraphEncoder.encode (graph_encoder.py:57-133) on the sequences of common.graph_sequences with one encoder
+    (its vocabulary grows across calls), plus the float64 centralities from the same networkx calls the reference
+    makes (graph_encoder.py:86-91) on the same graph, and the exception the reference raises on a sequence whose
+    Katz system is singular (ten self-transitions: 1 - 0.1 * 10 = 0 on an otherwise empty row)."""
+    class Data:      # stand-in for torch_geometric.data.Data (absent here): keeps the fields, validates nothing
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+
+        def validate(self, raise_on_error=True):
+            return True
+
+    sys.modules["torch_geometric.data"].Data = Data
+    import graph_encoder as ge
+    import networkx as nx
+    ge.Data = Data           # the module may already have been imported (by wgan_gp) with the empty stand-in
+    enc = ge.GraphEncoder()
+    out = {"networkx": nx.__version__}
+    for name, seq in common.graph_sequences():
+        graph, mapping = enc.encode(seq)
+        out[f"{name}.x"] = graph.x.clone()
+        out[f"{name}.edge_index"] = graph.edge_index.clone()
+        out[f"{name}.edge_features"] = graph.edge_features.clone()
+        out[f"{name}.num_nodes"] = graph.num_nodes
+        out[f"{name}.mapping_keys"] = list(mapping.keys())
+        out[f"{name}.mapping_values"] = list(mapping.values())
+        n = graph.num_nodes
+        f64 = torch.zeros(n, 4, dtype=torch.float64)
+        if n > 1:
+            G = nx.DiGraph()
+            for i in range(len(seq) - 1):
+                u, v = mapping[seq[i]], mapping[seq[i + 1]]
+                if G.has_edge(u, v):
+                    G[u][v]["weight"] += 1
+                else:
+                    G.add_edge(u, v, weight=1)
+            b, c, p = nx.betweenness_centrality(G), nx.closeness_centrality(G), nx.pagerank(G, weight="weight")
+            k = nx.katz_centrality_numpy(G, weight="weight") if n > 2 else {i: 0 for i in G}
+            for i in range(n):
+                f64[i] = torch.tensor([k[i], b[i], c[i], p[i]], dtype=torch.float64)
+        out[f"{name}.f64"] = f64
+    out["vocab_keys"] = list(enc.syscall_vocabs.keys())
+    out["vocab_values"] = list(enc.syscall_vocabs.values())
+    singular = [1] * 11 + [2, 3]
+    try:
+        ge.GraphEncoder().encode(singular)
+        out["singular.raises"] = ""
+    except Exception as e:      # noqa: BLE001
+        out["singular.raises"] = type(e).__name__
+    try:
+        ge.GraphEncoder().encode([])
+        out["empty.raises"] = ""
+    except Exception as e:      # noqa: BLE001
+        out["empty.raises"] = f"{type(e).__name__}: {e}"
+    print("g13:", {k: v for k, v in out.items() if k.endswith("raises") or k.endswith("num_nodes")})
+    save("g13_graph_encoder.pt", out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
@@ -531,7 +589,7 @@ def main():
     a = ap.parse_args()
     torch.manual_seed(0)
     ref = import_reference()
-    todo = [g1_sampler, g2_generator, g3_critic, g4_gp, g5_ce, g6_adam, g7_full_step, g10_generate_fake_data, g11_attention, g12_wgan_clip]
+    todo = [g1_sampler, g2_generator, g3_critic, g4_gp, g5_ce, g6_adam, g7_full_step, g10_generate_fake_data, g11_attention, g12_wgan_clip, g13_graph_encoder]
     if a.full:
         todo += [g8_full_size, g9_full_step_full_size]
     for fn in todo:

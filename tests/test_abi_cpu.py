@@ -14,7 +14,7 @@ def header_decls():
     text = open(os.path.join(ROOT, "include", "s2g.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     out = {}
-    for m in re.finditer(r"\bint\s+(s2g_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
+    for m in re.finditer(r"\b(?:int|long)\s+(s2g_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
         args = m.group(2).strip()
         out[m.group(1)] = 0 if args in ("", "void") else args.count(",") + 1
     return out

@@ -1,0 +1,103 @@
+"""Sequence -> graph encoding on the device against the outputs recorded from the reference's GraphEncoder
+(graph_encoder.py:57-133; tests/golden/g13_graph_encoder.pt) and against the CPU restatement on batches."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(HERE, "golden"))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "sequence-to-graph-gan_amd"))
+
+import common  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+G13 = torch.load(os.path.join(HERE, "golden", "g13_graph_encoder.pt"), weights_only=True)
+
+
+def test_encoder_matches_reference_outputs():
+    import graph_encoder
+    enc = graph_encoder.GraphEncoder()
+    for name, seq in common.graph_sequences():
+        graph, mapping = enc.encode(seq)
+        assert graph.num_nodes == G13[f"{name}.num_nodes"], name
+        assert list(mapping.keys()) == G13[f"{name}.mapping_keys"], name
+        assert list(mapping.values()) == G13[f"{name}.mapping_values"], name
+        gx = G13[f"{name}.x"]
+        assert graph.x.dtype == gx.dtype and graph.x.shape == gx.shape, name
+        # float32 node features: the float64 values agree to ~1e-13, so at most the last float32 bit differs
+        np.testing.assert_allclose(graph.x.numpy(), gx.numpy(), rtol=3e-7, atol=1e-9, err_msg=name)
+        assert torch.equal(graph.edge_index, G13[f"{name}.edge_index"]), name
+        assert torch.equal(graph.edge_features, G13[f"{name}.edge_features"]), name
+    assert list(enc.syscall_vocabs.keys()) == G13["vocab_keys"]
+    assert list(enc.syscall_vocabs.values()) == G13["vocab_values"]
+
+
+def test_batch_equals_single_and_float64_values():
+    import graph_encoder
+    from s2g import graph
+    seqs = common.graph_sequences()
+    enc = graph_encoder.GraphEncoder()
+    batch = enc.encode_batch([s for _, s in seqs])
+    enc1 = graph_encoder.GraphEncoder()
+    for (name, seq), (gb, mb) in zip(seqs, batch):
+        g1, m1 = enc1.encode(seq)
+        assert m1 == mb and torch.equal(g1.x, gb.x) and torch.equal(g1.edge_index, gb.edge_index), name
+    # float64 features by symbol id against the recorded networkx values
+    for name, seq in seqs:
+        if not all(isinstance(s, int) and 0 <= s < 175 for s in seq):
+            continue
+        tok = torch.tensor([seq], dtype=torch.int32, device="cuda:0")
+        feat, info = graph.graph_features(tok, None, vocab=175)
+        keys, vals = G13[f"{name}.mapping_keys"], G13[f"{name}.mapping_values"]
+        ref = G13[f"{name}.f64"]
+        got = feat[0].cpu()[torch.tensor(keys)][torch.argsort(torch.tensor(vals))]
+        assert int(info[0, 0]) == len(keys) and int(info[0, 1]) == 0, name
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-9, atol=1e-13, err_msg=name)
+        absent = torch.ones(175, dtype=torch.bool)
+        absent[torch.tensor(keys)] = False
+        assert float(feat[0].cpu()[absent].abs().max()) == 0.0 if absent.any() else True
+
+
+def test_error_cases():
+    import graph_encoder
+    enc = graph_encoder.GraphEncoder()
+    assert G13["singular.raises"] == "LinAlgError"
+    with pytest.raises(np.linalg.LinAlgError):
+        enc.encode([1] * 11 + [2, 3])
+    with pytest.raises(ValueError, match="Sequence is empty."):
+        enc.encode([])
+    strs = ["open", "read", "read", "write", "close", "open", "mmap", "read", "close"]
+    g, m = enc.encode(strs)      # arbitrary hashable symbols; node order is the interpreter's set order
+    from oracle import graph_cpu
+    f, unique, mapping = graph_cpu.features(strs)
+    assert m == mapping
+    np.testing.assert_allclose(g.x[:, 1:].numpy(), f.astype(np.float32), rtol=3e-7, atol=1e-9)
+
+
+@pytest.mark.parametrize("skew,V,L,N", [(False, 175, 512, 24), (True, 175, 512, 24), (True, 60, 200, 40), (False, 256, 700, 6),
+                                        (False, 7, 33, 50)])
+def test_batches_against_cpu_restatement(skew, V, L, N):
+    from oracle import graph_cpu
+    from s2g import graph
+    tok, lengths = common.graph_token_batch(21 + V, N, L, vocab=V, skew=skew)
+    feat, info = graph.graph_features(tok.cuda(), lengths.cuda(), vocab=V)
+    feat, info = feat.cpu().numpy(), info.cpu().numpy()
+    for r in range(N):
+        seq = tok[r, : int(lengths[r])].tolist()
+        try:
+            f, unique, mapping = graph_cpu.features(seq)
+        except np.linalg.LinAlgError:
+            assert info[r, 1] & 2
+            continue
+        assert info[r, 0] == len(unique) and info[r, 1] == 0, (r, info[r])
+        got = feat[r][np.array(unique)]
+        # Katz: two LU factorisations of a matrix whose condition number can reach ~1e6 with these counts
+        np.testing.assert_allclose(got[:, 1:], f[:, 1:], rtol=1e-9, atol=1e-13, err_msg=f"row {r}")
+        np.testing.assert_allclose(got[:, 0], f[:, 0], rtol=1e-6, atol=1e-9, err_msg=f"row {r} katz")
+        edges = len({(a, b) for a, b in zip(seq[:-1], seq[1:])})
+        assert info[r, 3] == edges
