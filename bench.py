@@ -198,6 +198,57 @@ def bench_wgan_clip(steps, warmup):
                                              "Adam + clamp, B=128, dropout 0.3"}}), flush=True)
 
 
+def bench_graph(steps, warmup, cpu_seconds=10.0):
+    """The step after the hot path (reference graph_encoder.py:57-133): node features of the transition graphs of
+    a batch of generated-length sequences (L = 512, V = 175), device-resident tokens in, [N, V, 4] float64
+    features out.  One step = one s2g_graph_features launch over N = 1024 sequences.  Two symbol distributions:
+    uniform draws (what an untrained generator emits: ~166 distinct symbols, Katz matrix in the global workspace)
+    and skewed draws (trace-like: a few dozen distinct symbols, Katz matrix in LDS).  The CPU figure is the
+    numpy restatement of the networkx algorithms on one core.  One JSON line of its own."""
+    import common
+    from oracle import graph_cpu
+    from s2g import graph
+    dev = torch.device("cuda", 0)
+    N, Lg, Vg = 1024, 512, 175
+    res = {}
+    for name, skew in (("uniform", False), ("skewed", True)):
+        tok, _ = common.graph_token_batch(77, N, Lg, vocab=Vg, skew=skew)
+        tokd = tok.to(dev)
+        for _ in range(warmup):
+            graph.graph_features(tokd, None, vocab=Vg)
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        t0 = time.perf_counter()
+        ev[0].record()
+        for _ in range(steps):
+            feat, info = graph.graph_features(tokd, None, vocab=Vg)
+        ev[1].record()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        inf = info.cpu()
+        t1, cnt = time.perf_counter(), 0
+        while time.perf_counter() - t1 < cpu_seconds / 2 and cnt < N:
+            try:
+                graph_cpu.features(tok[cnt].tolist())
+            except Exception:      # noqa: BLE001  (a singular Katz system: still a timed graph)
+                pass
+            cnt += 1
+        cpu = cnt / (time.perf_counter() - t1)
+        res[name] = {"graphs_per_s": N / dt, "ms_per_launch": dt * 1e3, "kernel_ms": ev[0].elapsed_time(ev[1]) / steps,
+                     "mean_nodes": float(inf[:, 0].float().mean()), "mean_edges": float(inf[:, 3].float().mean()),
+                     "mean_pagerank_iterations": float(inf[:, 2].float().mean()),
+                     "flagged": int((inf[:, 1] != 0).sum()), "cpu_graphs_per_s": cpu, "cpu_sample": f"{cnt} graphs, 1 core"}
+    u = res["uniform"]
+    print(json.dumps({"metric": "sequence-to-graph node-feature graphs/sec at V=175 L=512", "value": u["graphs_per_s"],
+                      "unit": "graphs/s", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": u["ms_per_launch"],
+                      "higher_is_better": True, "dtype": "f64", "data": "synthetic",
+                      "config": {"workload": "GraphEncoder centralities (betweenness, closeness, pagerank, katz), 1024 "
+                                             "sequences of 512 uniform symbols over 175 per launch"},
+                      "cpu_baseline": {"value": u["cpu_graphs_per_s"], "unit": "graphs/s", "cores": 1, "kind": "port",
+                                       "sample": u["cpu_sample"]},
+                      "by_distribution": res}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -210,9 +261,9 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="f32 (default, the headline): exact-fp32 MFMA everywhere; bf16: bf16 operands / fp32 accumulation "
                          "in the critic's input-layer products (the 2e-2 path)")
-    ap.add_argument("--variant", default="wgan_gp", choices=["wgan_gp", "attention", "wgan_clip"],
+    ap.add_argument("--variant", default="wgan_gp", choices=["wgan_gp", "attention", "wgan_clip", "graph"],
                     help="wgan_gp (default): the WGAN-GP step; attention: the transformer.py attention module alone; "
-                         "wgan_clip: the critic update of the weight-clipping variant (wgan.py) at L=1024, B=128")
+                         "wgan_clip: the critic update of the weight-clipping variant (wgan.py) at L=1024, B=128; graph: sequence -> graph node features (graph_encoder.py) for 1024 sequences")
     ap.add_argument("--path", default="trainer", choices=["trainer", "train_wgan"],
                     help="which path `value` is measured on: WGANGPTrainer.full_step on device-resident batches "
                          "(default, the headline) or the drop-in train_wgan() loop of wgan_gp.py on a CPU loader; "
@@ -228,6 +279,11 @@ def main():
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
         bench_wgan_clip(a.steps, a.warmup)
+        return
+    if a.variant == "graph":
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
+        bench_graph(a.steps, a.warmup)
         return
     from s2g import lib
     from s2g.parallel import init_from_env

@@ -7,20 +7,30 @@
 //   pagerank     x <- 0.85 (x A + dangling mass / n) + 0.15 / n on the row-normalised weights, until the
 //                L1 change is below n * 1e-6 (at most 100 iterations)
 //   katz         solve (I - 0.1 W^T) c = 1 (dense LU, partial pivoting), c / (sign(sum c) ||c||_2); n > 2 only
-// ONE workgroup of 256 threads per sequence, everything in float64 like the reference.  The graph lives in
-// LDS: transition counts as packed 16-bit pairs while the structures are derived (in/out neighbour
-// bitmasks, the in-edge lists of the pagerank product), then the same bytes hold the traversal state.
-// Brandes and the closeness distances share one breadth-first search per source; the four waves take
-// sources s = wave, wave + 4, ... and keep their sums in registers (a lane owns nodes lane, lane + 64, ...).
-// The Katz matrix is n x n float64 (245 KB at n = 175): it is factorised in LDS when it fits beside the
-// rest and in a caller-provided global workspace (L2-resident) otherwise, through the same code.
+// ONE workgroup of 16 waves per sequence, everything in float64 like the reference; every phase is a chain of
+// short dependent steps (LDS round trips, barriers), so the design is about waves in flight, not arithmetic:
+//   build    transition counts as packed 16-bit pairs in LDS (atomics), then in/out neighbour bitmasks and the
+//            in-edge lists of the pagerank product
+//   traverse waves 1..15 run Brandes' algorithm, one source per wave at a time (sources s = w-1, w+14, ...):
+//            a level-synchronous breadth-first search over the bitmasks (a lane owns nodes lane, lane+64, ...;
+//            path counts and dependencies of the wave's source in LDS), which also yields the closeness
+//            distances; wave 0 runs the whole pagerank iteration beside them with wave-level reductions only
+//   solve    the Katz system by LU with partial pivoting on a matrix held in REGISTERS: thread (ty, tx) of a
+//            32 x 32 grid owns rows 32 i + ty, columns 32 j + tx (6 x 6 values for n <= 192).  Rows are never
+//            moved: a finished-rows mask and a position table reproduce LAPACK's pivot order.  The owners of
+//            column k are one half-wave, so the pivot search is a 5-step shuffle; multipliers and the pivot row
+//            go through LDS: two barriers per elimination step.  Graphs with more than 192 nodes use a matrix
+//            in a caller-provided global workspace (L2-resident) instead.
 // Node numbering: ascending symbol id (every quantity above is independent of the numbering except for
 // the order of floating-point sums, which differs from networkx's in the last bits).
 #pragma once
 #include "s2g_common.h"
 
-#define GR_THREADS 256
+#define GR_THREADS 1024
+#define GR_WAVES 16
 #define GR_NMAX 256               // nodes per graph
+#define GR_T 6                    // LU register tile
+#define GR_LU_NMAX (32 * GR_T)    // largest graph of the register path
 #define GR_LDS_LIMIT 163840       // 160 KB per workgroup on gfx950
 
 struct GraphArgs {
@@ -30,22 +40,26 @@ struct GraphArgs {
   double* feat;           // [n_seq][V][4]: katz, betweenness, closeness, pagerank at the symbol's id; 0 if absent
   int* info;              // [n_seq][4]: nodes, status (bit 0: pagerank did not converge, bit 1: Katz matrix
                           //             singular), pagerank iterations, distinct edges
-  double* work;           // [n_seq][V*V] Katz matrices that do not fit in LDS
+  double* work;           // [n_seq][V*V] Katz matrices of graphs with more than GR_LU_NMAX nodes
   int ecap;               // capacity of the in-edge lists (distinct edges <= L - 1)
-  int uni_bytes;          // size of the LDS region shared by the count matrix and the later phases
+  int state_off;          // offset of the traversal / solver state inside the shared region: behind the count
+                          // matrix (V <= GR_LU_NMAX: the solver reads the counts) or 0 (it overlays the counts)
 };
 
 // byte offsets of the LDS regions (shared by the host, which sizes the allocation, and the kernel)
 struct GraphLds {
   int idx, sym, misc, red, inmask, outmask, invs, colptr, eval, esrc, uni, total;
 };
-__host__ __device__ inline GraphLds graph_lds_layout(int V, int ecap, int uni_bytes) {
+__host__ __device__ inline int graph_cnt_bytes(int V) { return (2 * V * V + 4 + 15) & ~15; }
+// sigma[16][V], coeff[16][V], x[V], bvec[V], lmul[2][V], prow[V], sol[V] doubles; reach, tot, pos, rowat, perm ints
+__host__ __device__ inline int graph_state_bytes(int V) { return (8 * (32 * V + 6 * V) + 4 * 5 * V + 15) & ~15; }
+__host__ __device__ inline GraphLds graph_lds_layout(int V, int ecap, int state_off) {
   GraphLds o;
   int p = 0;
   o.idx = p; p += 4 * GR_NMAX;
   o.sym = p; p += 4 * GR_NMAX;
-  o.misc = p; p += 4 * 16;
-  o.red = p; p += 8 * 16;
+  o.misc = p; p += 4 * 32;
+  o.red = p; p += 8 * 32;
   o.inmask = p; p += 32 * V;
   o.outmask = p; p += 32 * V;
   o.invs = p; p += 8 * V;
@@ -53,37 +67,166 @@ __host__ __device__ inline GraphLds graph_lds_layout(int V, int ecap, int uni_by
   o.colptr = p; p += 4 * (V + 2);
   o.esrc = p; p += 2 * ecap;
   p = (p + 15) & ~15;
-  o.uni = p; p += uni_bytes;
+  o.uni = p;
+  const int a = graph_cnt_bytes(V), b = state_off + graph_state_bytes(V);
+  p += a > b ? a : b;
   o.total = p;
   return o;
 }
-// bytes of the phase-two state at the head of the shared region (the Katz matrix may follow it)
-__host__ __device__ inline int graph_state_bytes(int V) {
-  // sigma[4][V], coeff[4][V], bet[4][V] doubles; reach[4][V], tot[4][V] ints; x[V], bvec[V], lmul[V], prow[V],
-  // sol[V] doubles; perm[V] ints
-  return ((8 * (12 * V + 5 * V) + 4 * (8 * V + V)) + 15) & ~15;
-}
 
-__device__ __forceinline__ double gr_block_sum(double v, double* red) {
+__device__ __forceinline__ double gr_wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+// sum over the workgroup, the same value (bit for bit) in every thread
+__device__ __forceinline__ double gr_block_sum(double v, double* red) {
+  v = gr_wave_sum(v);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
-  return (red[0] + red[1]) + (red[2] + red[3]);
+  double s = 0.0;
+#pragma unroll
+  for (int w = 0; w < GR_WAVES; ++w) s += red[w];
+  return s;
 }
 
 __device__ __forceinline__ unsigned gr_cnt(const unsigned* cnt32, int e) { return (cnt32[e >> 1] >> (16 * (e & 1))) & 0xffffu; }
+
+// element `which` of a register array as a sum of masked terms (a chain of selects on the index gets rewritten
+// by the compiler into a dynamically indexed array, i.e. the whole tile in scratch memory)
+__device__ __forceinline__ double gr_pick(const double (&v)[GR_T], int which) {
+  double r = 0.0;
+#pragma unroll
+  for (int j = 0; j < GR_T; ++j) r += (which == j) ? v[j] : 0.0;
+  return r;
+}
+
+struct GrSolve {      // LDS state of the Katz solver
+  double *bvec, *lmul, *prow, *sol;
+  int *pos, *rowat;
+  volatile int* misc;
+  int n, V;
+};
+
+// Elimination steps k = 32 KJ .. 32 KJ + 31 (the column index inside the register tile is the constant KJ).
+// Returns true when a zero pivot column was met.
+template <int KJ>
+__device__ __forceinline__ bool gr_lu_steps(double (&m)[GR_T][GR_T], unsigned& fin, const GrSolve& z, int tx, int ty) {
+#pragma clang fp contract(off)
+  const int n = z.n;
+  for (int kc = 0; kc < 32; ++kc) {
+    const int k = 32 * KJ + kc;
+    if (k >= n) break;
+    double* lm = z.lmul + (k & 1) * z.V;
+    if (tx == kc) {      // a half-wave: the owners of column k
+      // pivot: largest magnitude among the unfinished rows, the row LAPACK's row order lists first on ties
+      double bv = -1.0, bs = 0.0;
+      int bp = 0x7fffffff, br = -1;
+#pragma unroll
+      for (int i = 0; i < GR_T; ++i) {
+        if (!((fin >> i) & 1u)) {
+          const int r = 32 * i + ty;
+          const double av = fabs(m[i][KJ]);
+          const int ps = z.pos[r];
+          if (av > bv || (av == bv && ps < bp)) { bv = av; bp = ps; br = r; bs = m[i][KJ]; }
+        }
+      }
+#pragma unroll
+      for (int o = 16; o; o >>= 1) {
+        const double ov = __shfl_xor(bv, o), os = __shfl_xor(bs, o);
+        const int op = __shfl_xor(bp, o), orow = __shfl_xor(br, o);
+        if (ov > bv || (ov == bv && op < bp)) { bv = ov; bp = op; br = orow; bs = os; }
+      }
+      if (!(bv > 0.0)) {
+        if (ty == 0) z.misc[12] = 1;
+      } else {
+        const double rinv = 1.0 / bs;
+        const double bk = z.bvec[br];
+#pragma unroll
+        for (int i = 0; i < GR_T; ++i) {
+          const int r = 32 * i + ty;
+          double l = 0.0;
+          if (!((fin >> i) & 1u) && r != br) {
+            l = m[i][KJ] * rinv;
+            z.bvec[r] -= l * bk;
+          }
+          if (r < n) lm[r] = l;
+        }
+        if (ty == 0) {
+          z.misc[13] = br;
+          const int p = z.pos[br], rk = z.rowat[k];
+          z.pos[br] = k; z.pos[rk] = p; z.rowat[k] = br; z.rowat[p] = rk;
+        }
+      }
+    }
+    __syncthreads();
+    if (z.misc[12]) return true;      // uniform
+    const int pk = __builtin_amdgcn_readfirstlane(z.misc[13]);
+    if (ty == (pk & 31)) {
+      const int ip = pk >> 5;
+#pragma unroll
+      for (int i = 0; i < GR_T; ++i) {
+        if (ip == i) {      // scalar test: a branch around plain stores of row i
+#pragma unroll
+          for (int j = 0; j < GR_T; ++j) {
+            const int c = 32 * j + tx;
+            if (c < n) z.prow[c] = m[i][j];
+          }
+        }
+      }
+      fin |= 1u << ip;
+    }
+    __syncthreads();
+    double l[GR_T], p[GR_T];
+#pragma unroll
+    for (int i = 0; i < GR_T; ++i) { const int r = 32 * i + ty; l[i] = r < n ? lm[r] : 0.0; }
+#pragma unroll
+    for (int j = 0; j < GR_T; ++j) { const int c = 32 * j + tx; p[j] = (c < n && c > k) ? z.prow[c] : 0.0; }
+#pragma unroll
+    for (int i = 0; i < GR_T; ++i)
+#pragma unroll
+      for (int j = 0; j < GR_T; ++j) m[i][j] -= l[i] * p[j];
+  }
+  return false;
+}
+
+// Back substitution for the unknowns k = 32 KJ + 31 .. 32 KJ, each inside the half-wave that owns column k:
+// c_k = b / U_kk on the pivot row of step k, then b_r -= U_rk c_k on the pivot rows of earlier steps.
+template <int KJ>
+__device__ __forceinline__ void gr_back_steps(const double (&m)[GR_T][GR_T], const GrSolve& z, int tx, int ty, int lane) {
+#pragma clang fp contract(off)
+  const int n = z.n;
+  for (int kc = 31; kc >= 0; --kc) {
+    const int k = 32 * KJ + kc;
+    if (k >= n) continue;
+    if (tx == kc) {
+      const int pk = __builtin_amdgcn_readfirstlane(z.rowat[k]), ip = pk >> 5;
+      double col[GR_T];
+#pragma unroll
+      for (int i = 0; i < GR_T; ++i) col[i] = m[i][KJ];
+      const double mine = (ty == (pk & 31)) ? z.bvec[pk] / gr_pick(col, ip) : 0.0;
+      const double xk = __shfl(mine, (lane & 32) + (pk & 31));
+#pragma unroll
+      for (int i = 0; i < GR_T; ++i) {
+        const int r = 32 * i + ty;
+        if (r < n && z.pos[r] < k) z.bvec[r] -= col[i] * xk;
+      }
+      if (ty == 0) z.sol[k] = xk;
+    }
+    __syncthreads();
+  }
+}
 
 extern "C" __global__ __launch_bounds__(GR_THREADS) void s2g_k_graph_features(GraphArgs a) {
 #pragma clang fp contract(off)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int V = a.V;
-  const GraphLds lo = graph_lds_layout(V, a.ecap, a.uni_bytes);
+  const GraphLds lo = graph_lds_layout(V, a.ecap, a.state_off);
   int* idx = reinterpret_cast<int*>(smem + lo.idx);
   int* sym = reinterpret_cast<int*>(smem + lo.sym);
-  int* misc = reinterpret_cast<int*>(smem + lo.misc);
+  volatile int* misc = reinterpret_cast<int*>(smem + lo.misc);
   double* red = reinterpret_cast<double*>(smem + lo.red);
   unsigned long long* inmask = reinterpret_cast<unsigned long long*>(smem + lo.inmask);
   unsigned long long* outmask = reinterpret_cast<unsigned long long*>(smem + lo.outmask);
@@ -99,20 +242,20 @@ extern "C" __global__ __launch_bounds__(GR_THREADS) void s2g_k_graph_features(Gr
   int* info = a.info + 4 * g;
   for (int i = tid; i < 4 * V; i += GR_THREADS) feat[i] = 0.0;
 
-  // ---- nodes: the distinct symbols, numbered in ascending order
-  idx[tid] = 0;
+  // ---- nodes: the distinct symbols, numbered in ascending order (threads 0..255 = waves 0..3 hold one symbol each)
+  if (tid < GR_NMAX) idx[tid] = 0;
   __syncthreads();
   for (int i = tid; i < len; i += GR_THREADS) idx[min(max(tk[i], 0), V - 1)] = 1;
   __syncthreads();
-  const int present = idx[tid];
+  const int present = tid < GR_NMAX ? idx[tid] : 0;
   const unsigned long long bal = __ballot(present);
   const int within = __popcll(bal & ((1ull << lane) - 1ull));
-  if (lane == 0) misc[wv] = __popcll(bal);
+  if (lane == 0 && wv < 4) misc[wv] = __popcll(bal);
   __syncthreads();
   int base = 0;
-  for (int w = 0; w < wv; ++w) base += misc[w];
+  for (int w = 0; w < wv && w < 4; ++w) base += misc[w];
   const int n = misc[0] + misc[1] + misc[2] + misc[3];
-  idx[tid] = present ? base + within : -1;
+  if (tid < GR_NMAX) idx[tid] = present ? base + within : -1;
   if (present) sym[base + within] = tid;
   __syncthreads();
   if (n < 2) {      // no node or a single one: the reference assigns zeros (graph_encoder.py:112-120)
@@ -132,7 +275,7 @@ extern "C" __global__ __launch_bounds__(GR_THREADS) void s2g_k_graph_features(Gr
   }
   __syncthreads();
 
-  // ---- neighbour bitmasks (bit j of word q = node 64 q + j), row sums, in-edge lists, Katz matrix
+  // ---- neighbour bitmasks (bit j of word q = node 64 q + j), row sums, in-edge lists
   for (int t = tid; t < 4 * n; t += GR_THREADS) {
     const int i = t >> 2, q = t & 3;
     unsigned long long mo = 0ull, mi = 0ull;
@@ -160,10 +303,10 @@ extern "C" __global__ __launch_bounds__(GR_THREADS) void s2g_k_graph_features(Gr
       const int up = __shfl_up(inc, o);
       if (lane >= o) inc += up;
     }
-    if (lane == 63) misc[4 + wv] = inc;
+    if (lane == 63 && wv < 4) misc[4 + wv] = inc;
     __syncthreads();
     int off = 0;
-    for (int w = 0; w < wv; ++w) off += misc[4 + w];
+    for (int w = 0; w < wv && w < 4; ++w) off += misc[4 + w];
     const int start = off + inc - deg;
     if (tid < n) colptr[tid] = start;
     if (tid == n - 1) colptr[n] = start + deg;
@@ -181,71 +324,124 @@ extern "C" __global__ __launch_bounds__(GR_THREADS) void s2g_k_graph_features(Gr
       }
     }
   }
+#ifdef GR_SKIP_KATZ
+  const bool want_katz = false;
+#else
   const bool want_katz = n > 2;
-  const int state_bytes = graph_state_bytes(V);
-  const bool mat_in_lds = (long)state_bytes + 8L * nn <= (long)a.uni_bytes;
+#endif
+  const bool lu_regs = n <= GR_LU_NMAX && a.state_off > 0;      // the register path reads the counts later
   double* Mg = a.work + (size_t)g * V * V;
-  if (want_katz) {
+  if (want_katz && !lu_regs) {
     // M = I - 0.1 W^T, row-major with row stride n: M[r][c] = [r == c] - 0.1 * count(c -> r)
-    for (int r = wv; r < n; r += 4)
+    for (int r = wv; r < n; r += GR_WAVES)
       for (int c = lane; c < n; c += 64) Mg[r * n + c] = (r == c ? 1.0 : 0.0) - 0.1 * (double)gr_cnt(cnt32, c * n + r);
   }
-  __syncthreads();      // the count matrix is dead from here on: its bytes become the state below
+  __syncthreads();      // with state_off == 0 the count matrix is dead from here on: its bytes become the state below
 
-  double* sigma = reinterpret_cast<double*>(uni);      // [4][V]
-  double* coeff = sigma + 4 * V;                        // [4][V]
-  double* betp = coeff + 4 * V;                         // [4][V]
-  double* xv = betp + 4 * V;                            // [V]
+  char* st = uni + a.state_off;
+  double* sigma = reinterpret_cast<double*>(st);        // [16][V]
+  double* coeff = sigma + GR_WAVES * V;                 // [16][V]
+  double* xv = coeff + GR_WAVES * V;                    // [V]
   double* bvec = xv + V;
-  double* lmul = bvec + V;
-  double* prow = lmul + V;
+  double* lmul = bvec + V;                              // [2][V]
+  double* prow = lmul + 2 * V;
   double* sol = prow + V;
-  int* reachp = reinterpret_cast<int*>(sol + V);        // [4][V]
-  int* totp = reachp + 4 * V;                           // [4][V]
-  int* perm = totp + 4 * V;                             // [V]
-  double* Ml = reinterpret_cast<double*>(uni + state_bytes);
-  double* M = mat_in_lds ? Ml : Mg;
-  if (want_katz && mat_in_lds) {
-    for (int i = tid; i < nn; i += GR_THREADS) Ml[i] = Mg[i];
-  }
+  int* reach = reinterpret_cast<int*>(sol + V);         // [V]
+  int* tot = reach + V;
+  int* pos = tot + V;
+  int* rowat = pos + V;
+  int* perm = rowat + V;
+  if (tid < n) { reach[tid] = 0; tot[tid] = 0; }
+  __syncthreads();
 
-  // ---- Brandes betweenness + closeness: one breadth-first search per source, a wave per source
-  {
+  int status = 0, iters = 0;
+  if (wv == 0) {
+    // ---- pagerank on one wave: lane owns nodes lane + 64 k; no workgroup barrier inside
+    volatile double* x = xv;
+    const double p = 1.0 / (double)n;
+    double xo[4];
+    bool mine[4], dang[4];
+    int e0[4], e1[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int j = lane + 64 * k;
+      mine[k] = j < n;
+      dang[k] = mine[k] && invS[j] == 0.0;
+      e0[k] = mine[k] ? colptr[j] : 0;
+      e1[k] = mine[k] ? colptr[j + 1] : 0;
+      xo[k] = mine[k] ? p : 0.0;
+      if (mine[k]) x[j] = p;
+    }
+    bool done = false;
+    for (int it = 1; it <= 100 && !done; ++it) {
+      double dpart = 0.0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dpart += dang[k] ? xo[k] : 0.0;
+      const double dsum = gr_wave_sum(dpart);
+      double xn[4], epart = 0.0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        double t1 = 0.0;
+        for (int e = e0[k]; e < e1[k]; ++e) t1 += x[esrc[e]] * eval[e];
+        xn[k] = mine[k] ? 0.85 * (t1 + dsum * p) + (1.0 - 0.85) * p : 0.0;
+        epart += fabs(xn[k] - xo[k]);
+      }
+      const double err = gr_wave_sum(epart);      // every lane's gathers of x are complete before the stores below
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        xo[k] = xn[k];
+        if (mine[k]) x[lane + 64 * k] = xn[k];
+      }
+      iters = it;
+      done = err < (double)n * 1.0e-6;
+    }
+    if (!done) status |= 1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (mine[k]) feat[4 * sym[lane + 64 * k] + 3] = xo[k];
+  } else {
+    // ---- Brandes betweenness + closeness: one breadth-first search per source, a wave per source
     volatile double* sg = sigma + wv * V;
     volatile double* cf = coeff + wv * V;
+    const int nk = (n + 63) >> 6;      // node slots in use
     double bet[4] = {0.0, 0.0, 0.0, 0.0};
-    int reach[4] = {0, 0, 0, 0}, tot[4] = {0, 0, 0, 0};
-    for (int s = wv; s < n; s += 4) {
+    int rch[4] = {0, 0, 0, 0}, tt[4] = {0, 0, 0, 0};
+#ifdef GR_SKIP_BRANDES
+    for (int s = wv - 1; s < 0; s += GR_WAVES - 1) {
+#else
+    for (int s = wv - 1; s < n; s += GR_WAVES - 1) {
+#endif
       int dist[4];
       unsigned long long F[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const int v = lane + 64 * k;
-        dist[k] = (v == s) ? 0 : -1;
+        dist[k] = (lane + 64 * k == s) ? 0 : -1;
         F[k] = (s >> 6) == k ? 1ull << (s & 63) : 0ull;
       }
       if (lane == (s & 63)) sg[s] = 1.0;
       int d = 0;
       while (F[0] | F[1] | F[2] | F[3]) {      // at most n levels: every level marks at least one new node
-        unsigned long long nf[4];
+        unsigned long long nf[4] = {0ull, 0ull, 0ull, 0ull};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const int v = lane + 64 * k;
-          bool hit = false;
-          double acc = 0.0;
-          if (v < n && dist[k] < 0) {
+          if (k < nk) {
+            const int v = lane + 64 * k;
+            bool hit = false;
+            double acc = 0.0;
+            if (v < n && dist[k] < 0) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              unsigned long long m = inmask[4 * v + q] & F[q];
-              while (m) {
-                acc += sg[64 * q + __builtin_ctzll(m)];
-                m &= m - 1ull;
-                hit = true;
+              for (int q = 0; q < 4; ++q) {
+                unsigned long long m = inmask[4 * v + q] & F[q];
+                while (m) {
+                  acc += sg[64 * q + __builtin_ctzll(m)];
+                  m &= m - 1ull;
+                  hit = true;
+                }
               }
             }
+            if (hit) { dist[k] = d + 1; sg[v] = acc; }
+            nf[k] = __ballot(hit);
           }
-          if (hit) { dist[k] = d + 1; sg[v] = acc; }
-          nf[k] = __ballot(hit);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) F[k] = nf[k];
@@ -254,7 +450,7 @@ extern "C" __global__ __launch_bounds__(GR_THREADS) void s2g_k_graph_features(Gr
       const int dmax = d - 1;      // deepest level reached (the loop ran once more to find it empty)
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        if (dist[k] >= 0) { reach[k] += 1; tot[k] += dist[k]; }
+        if (dist[k] >= 0) { rch[k] += 1; tt[k] += dist[k]; }
       for (int lev = dmax; lev >= 0; --lev) {
         unsigned long long nxt[4];
 #pragma unroll
@@ -262,7 +458,7 @@ extern "C" __global__ __launch_bounds__(GR_THREADS) void s2g_k_graph_features(Gr
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int v = lane + 64 * k;
-          if (v < n && dist[k] == lev) {
+          if (k < nk && v < n && dist[k] == lev) {
             const double sv = sg[v];
             double dl = 0.0;
 #pragma unroll
@@ -280,18 +476,23 @@ extern "C" __global__ __launch_bounds__(GR_THREADS) void s2g_k_graph_features(Gr
         }
       }
     }
+    // the wave's sums: betweenness into its own (now idle) path-count row, the integer sums by atomics
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int v = lane + 64 * k;
-      if (v < n) { betp[wv * V + v] = bet[k]; reachp[wv * V + v] = reach[k]; totp[wv * V + v] = tot[k]; }
+      if (v < n) {
+        sg[v] = bet[k];
+        if (rch[k]) { atomicAdd(&reach[v], rch[k]); atomicAdd(&tot[v], tt[k]); }
+      }
     }
   }
   __syncthreads();
   if (tid < n) {
-    double b = ((betp[tid] + betp[V + tid]) + betp[2 * V + tid]) + betp[3 * V + tid];
+    double b = 0.0;
+#pragma unroll
+    for (int w = 1; w < GR_WAVES; ++w) b += sigma[w * V + tid];
     if (n > 2) b *= 1.0 / (double)((n - 1) * (n - 2));
-    const int r = reachp[tid] + reachp[V + tid] + reachp[2 * V + tid] + reachp[3 * V + tid];
-    const int t = totp[tid] + totp[V + tid] + totp[2 * V + tid] + totp[3 * V + tid];
+    const int r = reach[tid], t = tot[tid];
     double c = 0.0;
     if (t > 0) {
       c = ((double)r - 1.0) / (double)t;
@@ -300,40 +501,40 @@ extern "C" __global__ __launch_bounds__(GR_THREADS) void s2g_k_graph_features(Gr
     feat[4 * sym[tid] + 1] = b;
     feat[4 * sym[tid] + 2] = c;
   }
+  if (tid == 0) misc[12] = 0;      // singular flag of the solver
+  if (tid < n) { bvec[tid] = 1.0; pos[tid] = tid; rowat[tid] = tid; perm[tid] = tid; }
+  __syncthreads();
 
-  // ---- pagerank: power iteration on the row-normalised weights; thread j owns node j
-  int status = 0, iters = 0;
-  {
-    const double p = 1.0 / (double)n;
-    const bool mine = tid < n;
-    const bool dang = mine && invS[tid] == 0.0;
-    const int e0 = mine ? colptr[tid] : 0, e1 = mine ? colptr[tid + 1] : 0;
-    if (mine) xv[tid] = p;
-    __syncthreads();
-    bool done = false;
-    for (int it = 1; it <= 100 && !done; ++it) {
-      const double xo = mine ? xv[tid] : 0.0;
-      const double dsum = gr_block_sum(dang ? xo : 0.0, red);
-      double t1 = 0.0;
-      for (int e = e0; e < e1; ++e) t1 += xv[esrc[e]] * eval[e];
-      const double xn = mine ? 0.85 * (t1 + dsum * p) + (1.0 - 0.85) * p : 0.0;
-      const double err = gr_block_sum(fabs(xn - xo), red);      // its barriers order the reads above before the write
-      if (mine) xv[tid] = xn;
-      __syncthreads();
-      iters = it;
-      done = err < (double)n * 1.0e-6;
+  bool singular = false;
+  if (want_katz && lu_regs) {
+    // ---- Katz, matrix in registers: M[r][c] = [r == c] - 0.1 count(c -> r), r = 32 i + ty, c = 32 j + tx
+    const int tx = tid >> 5, ty = tid & 31;
+    double m[GR_T][GR_T];
+    unsigned fin = 0;      // bit i: row 32 i + ty is a finished pivot row (or lies beyond n)
+#pragma unroll
+    for (int i = 0; i < GR_T; ++i) {
+      const int r = 32 * i + ty;
+      if (r >= n) fin |= 1u << i;
+#pragma unroll
+      for (int j = 0; j < GR_T; ++j) {
+        const int c = 32 * j + tx;
+        const double e = (r == c) ? 1.0 : 0.0;
+        m[i][j] = (r < n && c < n) ? e - 0.1 * (double)gr_cnt(cnt32, c * n + r) : e;
+      }
     }
-    if (!done) status |= 1;
-    if (mine) feat[4 * sym[tid] + 3] = xv[tid];
-  }
-
-  // ---- Katz: LU with partial pivoting on M (rows addressed through perm), the right-hand side carried along
-  if (want_katz) {
-    if (tid < n) { perm[tid] = tid; bvec[tid] = 1.0; }
-    __syncthreads();
-    bool singular = false;
+    static_assert(GR_T == 6, "the calls below enumerate the six tile columns");
+    GrSolve z;
+    z.bvec = bvec; z.lmul = lmul; z.prow = prow; z.sol = sol; z.pos = pos; z.rowat = rowat; z.misc = misc; z.n = n; z.V = V;
+    singular = gr_lu_steps<0>(m, fin, z, tx, ty) || gr_lu_steps<1>(m, fin, z, tx, ty) || gr_lu_steps<2>(m, fin, z, tx, ty) ||
+               gr_lu_steps<3>(m, fin, z, tx, ty) || gr_lu_steps<4>(m, fin, z, tx, ty) || gr_lu_steps<5>(m, fin, z, tx, ty);
+    if (!singular) {
+      gr_back_steps<5>(m, z, tx, ty, lane); gr_back_steps<4>(m, z, tx, ty, lane); gr_back_steps<3>(m, z, tx, ty, lane);
+      gr_back_steps<2>(m, z, tx, ty, lane); gr_back_steps<1>(m, z, tx, ty, lane); gr_back_steps<0>(m, z, tx, ty, lane);
+    }
+  } else if (want_katz) {
+    // ---- Katz, matrix in the global workspace (rows addressed through perm), the right-hand side carried along
+    double* M = Mg;
     for (int k = 0; k < n && !singular; ++k) {
-      // pivot: largest |M[r][k]|, r >= k, first such row (LAPACK's choice)
       double best = -1.0;
       int bi = 0x7fffffff;
       if (tid >= k && tid < n) { best = fabs(M[perm[tid] * n + k]); bi = tid; }
@@ -343,13 +544,13 @@ extern "C" __global__ __launch_bounds__(GR_THREADS) void s2g_k_graph_features(Gr
         const int oi = __shfl_xor(bi, o);
         if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
       }
-      if (lane == 0) { red[8 + wv] = best; misc[8 + wv] = bi; }
+      if (lane == 0 && wv < 4) { red[16 + wv] = best; misc[16 + wv] = bi; }
       __syncthreads();
-      best = red[8]; bi = misc[8];
+      best = red[16]; bi = misc[16];
 #pragma unroll
       for (int w = 1; w < 4; ++w)
-        if (red[8 + w] > best || (red[8 + w] == best && misc[8 + w] < bi)) { best = red[8 + w]; bi = misc[8 + w]; }
-      if (best == 0.0) { singular = true; break; }      // uniform: every thread read the same four candidates
+        if (red[16 + w] > best || (red[16 + w] == best && misc[16 + w] < bi)) { best = red[16 + w]; bi = misc[16 + w]; }
+      if (!(best > 0.0)) { singular = true; break; }      // uniform: every thread read the same four candidates
       const int pk = perm[bi], pold = perm[k];
       __syncthreads();
       if (tid == 0) { perm[k] = pk; perm[bi] = pold; }
@@ -364,17 +565,19 @@ extern "C" __global__ __launch_bounds__(GR_THREADS) void s2g_k_graph_features(Gr
         prow[tid] = M[pk * n + tid];
       }
       __syncthreads();
-      for (int r = k + 1 + (tid >> 4); r < n; r += 16) {
+      for (int r = k + 1 + (tid >> 5); r < n; r += 32) {
         const int pr = perm[r];
         const double l = lmul[r];
-        for (int c = k + 1 + (tid & 15); c < n; c += 16) M[pr * n + c] -= l * prow[c];
+        const int c0 = k + 1 + (tid & 31);
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const int c = c0 + 32 * q; v[q] = c < n ? M[pr * n + c] : 0.0; }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const int c = c0 + 32 * q; if (c < n) M[pr * n + c] = v[q] - l * prow[c]; }
       }
       __syncthreads();
     }
-    if (singular) {
-      status |= 2;
-    } else {
-      // back substitution, column by column: c_k = b_k / U_kk, then b_r -= U_rk c_k for r < k
+    if (!singular) {
       for (int k = n - 1; k >= 0; --k) {
         const int pk = perm[k];
         const double xk = bvec[pk] / M[pk * n + k];
@@ -383,6 +586,13 @@ extern "C" __global__ __launch_bounds__(GR_THREADS) void s2g_k_graph_features(Gr
         if (tid == k) sol[k] = xk;
         __syncthreads();
       }
+    }
+  }
+  if (want_katz) {
+    if (singular) {
+      status |= 2;
+    } else {
+      // c / (sign(sum c) * ||c||_2)   (katz_centrality_numpy's normalisation)
       const double c = tid < n ? sol[tid] : 0.0;
       const double s = gr_block_sum(c, red);
       const double ss = gr_block_sum(c * c, red);
@@ -394,12 +604,9 @@ extern "C" __global__ __launch_bounds__(GR_THREADS) void s2g_k_graph_features(Gr
   if (tid == 0) { info[0] = n; info[1] = status; info[2] = iters; info[3] = colptr[n]; }
 }
 
-// dynamic LDS bytes of a launch, the shared region as large as the limit allows (more of the Katz matrices fit)
-static inline int graph_uni_bytes(int V, int ecap) {
-  const int fixed = graph_lds_layout(V, ecap, 0).total;
-  int need = 2 * V * V + 16;                              // count matrix
-  if (graph_state_bytes(V) > need) need = graph_state_bytes(V);
-  int room = GR_LDS_LIMIT - fixed;
-  room &= ~15;
-  return room >= need ? room : -1;
+// offset of the solver state inside the shared LDS region: behind the count matrix when both fit (the register
+// solver reads the counts after the traversal), else 0; < 0: the launch does not fit in LDS at all
+static inline int graph_state_off(int V, int ecap) {
+  if (V <= GR_LU_NMAX && graph_lds_layout(V, ecap, graph_cnt_bytes(V)).total <= GR_LDS_LIMIT) return graph_cnt_bytes(V);
+  return graph_lds_layout(V, ecap, 0).total <= GR_LDS_LIMIT ? 0 : -1;
 }

@@ -628,9 +628,9 @@ int s2g_graph_features(const int* tokens, const int* lengths, int n_seq, int L, 
   a.tokens = tokens; a.lengths = lengths; a.L = L; a.V = V; a.feat = feat; a.info = info; a.work = work;
   const long emax = (long)V * V < (long)L - 1 ? (long)V * V : (long)L - 1;
   a.ecap = emax < 1 ? 1 : (int)emax;
-  a.uni_bytes = graph_uni_bytes(V, a.ecap);
-  if (a.uni_bytes < 0) return -3;                             // the sequence's edge lists do not fit in LDS
-  const int lds = graph_lds_layout(V, a.ecap, a.uni_bytes).total;
+  a.state_off = graph_state_off(V, a.ecap);
+  if (a.state_off < 0) return -3;                             // the sequence's edge lists do not fit in LDS
+  const int lds = graph_lds_layout(V, a.ecap, a.state_off).total;
   static std::mutex mu;
   static int lds_set[64] = {0};
   int dev = 0;
