@@ -15,12 +15,13 @@
 //            a level-synchronous breadth-first search over the bitmasks (a lane owns nodes lane, lane+64, ...;
 //            path counts and dependencies of the wave's source in LDS), which also yields the closeness
 //            distances; wave 0 runs the whole pagerank iteration beside them with wave-level reductions only
-//   solve    the Katz system by LU with partial pivoting on a matrix held in REGISTERS: thread (ty, tx) of a
-//            32 x 32 grid owns rows 32 i + ty, columns 32 j + tx (6 x 6 values for n <= 192).  Rows are never
-//            moved: a finished-rows mask and a position table reproduce LAPACK's pivot order.  The owners of
-//            column k are one half-wave, so the pivot search is a 5-step shuffle; multipliers and the pivot row
-//            go through LDS: two barriers per elimination step.  Graphs with more than 192 nodes use a matrix
-//            in a caller-provided global workspace (L2-resident) instead.
+//   solve    the Katz system by Gauss-Jordan elimination with partial pivoting on a matrix held in REGISTERS:
+//            thread (ty, tx) of a 32 x 32 grid owns rows 32 i + ty, columns 32 j + tx (6 x 6 values for
+//            n <= 192).  Rows are never moved: a finished-rows mask and a position table reproduce LAPACK's
+//            pivot order.  The owners of column k are one half-wave, so the pivot search is four DPP steps and
+//            one shuffle; multipliers and the pivot row go through LDS, and the rank-1 update trails two steps
+//            behind the search (gr_gj_steps): one barrier per step.  Graphs with more than 192 nodes use LU on
+//            a matrix in a caller-provided global workspace (L2-resident) instead.
 // Node numbering: ascending symbol id (every quantity above is independent of the numbering except for
 // the order of floating-point sums, which differs from networkx's in the last bits).
 #pragma once
@@ -51,8 +52,8 @@ struct GraphLds {
   int idx, sym, misc, red, inmask, outmask, invs, colptr, eval, esrc, uni, total;
 };
 __host__ __device__ inline int graph_cnt_bytes(int V) { return (2 * V * V + 4 + 15) & ~15; }
-// sigma[16][V], coeff[16][V], x[V], bvec[V], lmul[2][V], prow[V], sol[V] doubles; reach, tot, pos, rowat, perm ints
-__host__ __device__ inline int graph_state_bytes(int V) { return (8 * (32 * V + 6 * V) + 4 * 5 * V + 15) & ~15; }
+// sigma[16][V], coeff[16][V], x[V], bvec[V], lmul[3][V], prow[2][V], sol[V] doubles; reach, tot, pos, rowat, perm ints
+__host__ __device__ inline int graph_state_bytes(int V) { return (8 * (32 * V + 8 * V) + 4 * 5 * V + 15) & ~15; }
 __host__ __device__ inline GraphLds graph_lds_layout(int V, int ecap, int state_off) {
   GraphLds o;
   int p = 0;
@@ -102,6 +103,15 @@ __device__ __forceinline__ double gr_pick(const double (&v)[GR_T], int which) {
   return r;
 }
 
+#ifdef GR_STAMPS      // development aid: shader-clock stamps into the (otherwise unused) workspace of graph 0
+#define GR_STAMP(slot) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) gr_stamp_buf[16 * (threadIdx.x >> 6) + (slot)] = (double)clock64(); } while (0)
+#define GR_ACC(slot, v) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) gr_stamp_buf[16 * (threadIdx.x >> 6) + (slot)] += (double)(v); } while (0)
+__device__ double* gr_stamp_buf;
+#else
+#define GR_STAMP(slot) do {} while (0)
+#define GR_ACC(slot, v) do {} while (0)
+#endif
+
 struct GrSolve {      // LDS state of the Katz solver
   double *bvec, *lmul, *prow, *sol;
   int *pos, *rowat;
@@ -109,113 +119,298 @@ struct GrSolve {      // LDS state of the Katz solver
   int n, V;
 };
 
-// Elimination steps k = 32 KJ .. 32 KJ + 31 (the column index inside the register tile is the constant KJ).
-// Returns true when a zero pivot column was met.
+template <int CTRL>
+__device__ __forceinline__ int gr_dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+template <int CTRL>
+__device__ __forceinline__ double gr_dpp_d(double v) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const unsigned lo = (unsigned)gr_dpp_i<CTRL>((int)(unsigned)b), hi = (unsigned)gr_dpp_i<CTRL>((int)(unsigned)(b >> 32));
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)lo);
+}
+// keep the better of two pivot candidates: larger magnitude, then the smaller key (position in LAPACK's row order)
+__device__ __forceinline__ void gr_better(double& bv, int& key, double ov, int okey) {
+  if (ov > bv || (ov == bv && okey < key)) { bv = ov; key = okey; }
+}
+
+// Gauss-Jordan steps with partial pivoting for the columns ks = 32 KJ .. 32 KJ + 31 of the register-tiled
+// matrix, ONE workgroup barrier per step.  Step s publishes (before barrier s) its pivot row, the
+// multipliers l_s[r] = M[r][s] / pivot of every other row and the updated right-hand side; the rank-1 update of
+// the rest of the matrix trails behind: iteration ks applies update ks-2 (its pivot row was put in LDS during
+// iteration ks-1), while the half-wave that owns column ks brings that one column up to date by itself (update
+// ks-2 from LDS, update ks-1 with the pivot-row element it holds) and searches pivot ks.  Eliminating above the
+// pivot as well costs nothing here (every thread updates its whole tile anyway) and leaves a diagonal system, so
+// there is no back substitution.  Returns true when a zero pivot column was met.
 template <int KJ>
-__device__ __forceinline__ bool gr_lu_steps(double (&m)[GR_T][GR_T], unsigned& fin, const GrSolve& z, int tx, int ty) {
-#pragma clang fp contract(off)
-  const int n = z.n;
+__device__ __forceinline__ bool gr_gj_steps(double (&m)[GR_T][GR_T], unsigned& fin, const GrSolve& z, int tx, int ty,
+                                            int lane) {
+  // fused multiply-adds are allowed here (LAPACK's kernels use them too); the other phases keep separate roundings
+  const int n = z.n, V = z.V;
   for (int kc = 0; kc < 32; ++kc) {
-    const int k = 32 * KJ + kc;
-    if (k >= n) break;
-    double* lm = z.lmul + (k & 1) * z.V;
-    if (tx == kc) {      // a half-wave: the owners of column k
+    const int ks = 32 * KJ + kc;
+    if (ks >= n) break;
+#ifdef GR_STAMPS
+    const long long st0 = clock64();
+    long long st1 = st0;
+#endif
+    int pkp = 0;      // pivot row of step ks - 1
+    if (ks >= 1) {
+      pkp = __builtin_amdgcn_readfirstlane(z.misc[13 + ((ks - 1) & 1)]);
+      if (ty == (pkp & 31)) fin |= 1u << (pkp >> 5);
+    }
+    const double* lm2 = z.lmul + ((ks + 1) % 3) * V;      // multipliers of step ks - 2
+    const double* lm1 = z.lmul + ((ks + 2) % 3) * V;      // multipliers of step ks - 1
+    double* lm0 = z.lmul + (ks % 3) * V;                   // multipliers of step ks (written here)
+    const double* pr2 = z.prow + (ks & 1) * V;             // pivot row of step ks - 2
+    double* pr1 = z.prow + ((ks + 1) & 1) * V;             // pivot row of step ks - 1 (written here)
+    if (tx == kc) {      // a half-wave: the owners of column ks; the other waves wait for what it publishes
+      __builtin_amdgcn_s_setprio(3);
+      // every LDS operand of the search is fetched up front (one round trip instead of one per use)
+      double l1[GR_T];
+      int ps[GR_T];
+#pragma unroll
+      for (int i = 0; i < GR_T; ++i) {
+        const int r = 32 * i + ty;
+        const bool ok = r < n;
+        l1[i] = (ks >= 1 && ok) ? lm1[r] : 0.0;
+        ps[i] = ok ? z.pos[r] : 0;
+      }
+      const double p2 = ks >= 2 ? pr2[ks] : 0.0;
+      const int rk = z.rowat[ks];
+#pragma unroll
+      for (int i = 0; i < GR_T; ++i) {
+        const int r = 32 * i + ty;
+        m[i][KJ] -= ((ks >= 2 && r < n) ? lm2[r] : 0.0) * p2;
+      }
+      if (ks >= 1) {
+        double col[GR_T];
+#pragma unroll
+        for (int i = 0; i < GR_T; ++i) col[i] = m[i][KJ];
+        const double p1 = __shfl(gr_pick(col, pkp >> 5), (lane & 32) + (pkp & 31));
+#pragma unroll
+        for (int i = 0; i < GR_T; ++i) m[i][KJ] -= l1[i] * p1;
+      }
       // pivot: largest magnitude among the unfinished rows, the row LAPACK's row order lists first on ties
       double bv = -1.0, bs = 0.0;
-      int bp = 0x7fffffff, br = -1;
+      int key = 0x7fffffff;
 #pragma unroll
       for (int i = 0; i < GR_T; ++i) {
         if (!((fin >> i) & 1u)) {
-          const int r = 32 * i + ty;
           const double av = fabs(m[i][KJ]);
-          const int ps = z.pos[r];
-          if (av > bv || (av == bv && ps < bp)) { bv = av; bp = ps; br = r; bs = m[i][KJ]; }
+          const int kk = (ps[i] << 8) | (32 * i + ty);
+          if (av > bv || (av == bv && kk < key)) { bv = av; key = kk; bs = m[i][KJ]; }
         }
       }
-#pragma unroll
-      for (int o = 16; o; o >>= 1) {
-        const double ov = __shfl_xor(bv, o), os = __shfl_xor(bs, o);
-        const int op = __shfl_xor(bp, o), orow = __shfl_xor(br, o);
-        if (ov > bv || (ov == bv && op < bp)) { bv = ov; bp = op; br = orow; bs = os; }
-      }
-      if (!(bv > 0.0)) {
+      double gv = bv;
+      int gk = key;
+      gr_better(gv, gk, gr_dpp_d<DPP_QUAD(1, 0, 3, 2)>(gv), gr_dpp_i<DPP_QUAD(1, 0, 3, 2)>(gk));
+      gr_better(gv, gk, gr_dpp_d<DPP_QUAD(2, 3, 0, 1)>(gv), gr_dpp_i<DPP_QUAD(2, 3, 0, 1)>(gk));
+      gr_better(gv, gk, gr_dpp_d<DPP_ROW_HALF_MIRROR>(gv), gr_dpp_i<DPP_ROW_HALF_MIRROR>(gk));
+      gr_better(gv, gk, gr_dpp_d<DPP_ROW_MIRROR>(gv), gr_dpp_i<DPP_ROW_MIRROR>(gk));
+      gr_better(gv, gk, __shfl_xor(gv, 16), __shfl_xor(gk, 16));
+      if (!(gv > 0.0)) {
         if (ty == 0) z.misc[12] = 1;
       } else {
-        const double rinv = 1.0 / bs;
+        const int br = gk & 255;
+        const int wl = (lane & 32) + (br & 31);      // the winner: its own best candidate is the pivot
+        const double piv = __shfl(bs, wl);
+        double bo[GR_T];      // right-hand side of this thread's rows: all reads first, then all writes
+#pragma unroll
+        for (int i = 0; i < GR_T; ++i) { const int r = 32 * i + ty; bo[i] = r < n ? z.bvec[r] : 0.0; }
         const double bk = z.bvec[br];
+        const double rinv = 1.0 / piv;
 #pragma unroll
         for (int i = 0; i < GR_T; ++i) {
           const int r = 32 * i + ty;
-          double l = 0.0;
-          if (!((fin >> i) & 1u) && r != br) {
-            l = m[i][KJ] * rinv;
-            z.bvec[r] -= l * bk;
+          if (r < n) {
+            const double l = (r != br) ? m[i][KJ] * rinv : 0.0;
+            lm0[r] = l;
+            if (r != br) z.bvec[r] = bo[i] - l * bk;
           }
-          if (r < n) lm[r] = l;
         }
         if (ty == 0) {
-          z.misc[13] = br;
-          const int p = z.pos[br], rk = z.rowat[k];
-          z.pos[br] = k; z.pos[rk] = p; z.rowat[k] = br; z.rowat[p] = rk;
+          const int p = gk >> 8;      // the pivot row's place in LAPACK's row order; it swaps with the row at place ks
+          z.misc[13 + (ks & 1)] = br;
+          z.sol[ks] = piv;
+          z.pos[br] = ks; z.pos[rk] = p; z.rowat[ks] = br; z.rowat[p] = rk;
         }
       }
+      __builtin_amdgcn_s_setprio(0);
+#ifdef GR_STAMPS
+      st1 = clock64();
+#endif
     }
-    __syncthreads();
-    if (z.misc[12]) return true;      // uniform
-    const int pk = __builtin_amdgcn_readfirstlane(z.misc[13]);
-    if (ty == (pk & 31)) {
-      const int ip = pk >> 5;
+    if (ks >= 2) {      // trailing update ks - 2 on the columns beyond ks: tile columns below KJ are finished
+      double l2[GR_T], p[GR_T];      // (read here, not before the search: the tile leaves few registers to hold them)
+#pragma unroll
+      for (int i = 0; i < GR_T; ++i) { const int r = 32 * i + ty; l2[i] = r < n ? lm2[r] : 0.0; }
+#pragma unroll
+      for (int j = KJ; j < GR_T; ++j) { const int c = 32 * j + tx; p[j] = (c < n && c > ks) ? pr2[c] : 0.0; }
+#pragma unroll
+      for (int i = 0; i < GR_T; ++i)
+#pragma unroll
+        for (int j = KJ; j < GR_T; ++j) m[i][j] -= l2[i] * p[j];
+    }
+    if (ks >= 1 && ty == (pkp & 31)) {      // pivot row of step ks - 1, now current through update ks - 2
+      const int ip = pkp >> 5;
 #pragma unroll
       for (int i = 0; i < GR_T; ++i) {
         if (ip == i) {      // scalar test: a branch around plain stores of row i
 #pragma unroll
-          for (int j = 0; j < GR_T; ++j) {
+          for (int j = KJ; j < GR_T; ++j) {
             const int c = 32 * j + tx;
-            if (c < n) z.prow[c] = m[i][j];
+            if (c < n) pr1[c] = m[i][j];
           }
         }
       }
-      fin |= 1u << ip;
     }
+#ifdef GR_STAMPS
+    const long long st2 = clock64();
+#endif
     __syncthreads();
-    double l[GR_T], p[GR_T];
-#pragma unroll
-    for (int i = 0; i < GR_T; ++i) { const int r = 32 * i + ty; l[i] = r < n ? lm[r] : 0.0; }
-#pragma unroll
-    for (int j = 0; j < GR_T; ++j) { const int c = 32 * j + tx; p[j] = (c < n && c > k) ? z.prow[c] : 0.0; }
-#pragma unroll
-    for (int i = 0; i < GR_T; ++i)
-#pragma unroll
-      for (int j = 0; j < GR_T; ++j) m[i][j] -= l[i] * p[j];
+#ifdef GR_STAMPS
+    GR_ACC(8, st1 - st0);                 // owner chain (only the owner wave's lane-0 half adds a nonzero value)
+    GR_ACC(9, st2 - st1);                 // trailing update + pivot-row store
+    GR_ACC(10, clock64() - st2);          // barrier wait
+#endif
+    if (z.misc[12]) return true;      // uniform
   }
   return false;
 }
 
-// Back substitution for the unknowns k = 32 KJ + 31 .. 32 KJ, each inside the half-wave that owns column k:
-// c_k = b / U_kk on the pivot row of step k, then b_r -= U_rk c_k on the pivot rows of earlier steps.
-template <int KJ>
-__device__ __forceinline__ void gr_back_steps(const double (&m)[GR_T][GR_T], const GrSolve& z, int tx, int ty, int lane) {
+template <int NS>
+__device__ __forceinline__ bool gr_any(const unsigned long long (&F)[NS]) {
+  unsigned long long a = 0ull;
+#pragma unroll
+  for (int k = 0; k < NS; ++k) a |= F[k];
+  return a != 0ull;
+}
+
+// Brandes' algorithm for the sources of wave wv (1..15) of a graph of at most 64 NS nodes: a lane owns nodes
+// lane + 64 k, k < NS.  Leaves the wave's betweenness sums in its row of sigma and adds its reach / distance
+// sums (closeness) into reach / tot.
+template <int NS>
+__device__ __forceinline__ void gr_brandes(int n, int V, int lane, int wv, const unsigned long long* inmask,
+                                           const unsigned long long* outmask, double* sigma, double* coeff, int* reach,
+                                           int* tot) {
 #pragma clang fp contract(off)
-  const int n = z.n;
-  for (int kc = 31; kc >= 0; --kc) {
-    const int k = 32 * KJ + kc;
-    if (k >= n) continue;
-    if (tx == kc) {
-      const int pk = __builtin_amdgcn_readfirstlane(z.rowat[k]), ip = pk >> 5;
-      double col[GR_T];
+    volatile double* sg = sigma + wv * V;
+    volatile double* cf = coeff + wv * V;
+    // the neighbour masks of this lane's nodes do not depend on the source: registers, not LDS reads per level
+    // (up to 192 nodes; the 32 mask words of a 256-node graph would not fit beside the rest and stay in LDS)
+    constexpr bool REGS = NS <= 3;
+    constexpr int NM = REGS ? NS : 1;
+    unsigned long long inm[NM][NM], outm[NM][NM];
+    if (REGS) {
 #pragma unroll
-      for (int i = 0; i < GR_T; ++i) col[i] = m[i][KJ];
-      const double mine = (ty == (pk & 31)) ? z.bvec[pk] / gr_pick(col, ip) : 0.0;
-      const double xk = __shfl(mine, (lane & 32) + (pk & 31));
+      for (int k = 0; k < NM; ++k) {
+        const int v = lane + 64 * k;
 #pragma unroll
-      for (int i = 0; i < GR_T; ++i) {
-        const int r = 32 * i + ty;
-        if (r < n && z.pos[r] < k) z.bvec[r] -= col[i] * xk;
+        for (int q = 0; q < NM; ++q) {
+          inm[k][q] = v < n ? inmask[4 * v + q] : 0ull;
+          outm[k][q] = v < n ? outmask[4 * v + q] : 0ull;
+        }
       }
-      if (ty == 0) z.sol[k] = xk;
     }
-    __syncthreads();
-  }
+    double bet[NS];
+    int rch[NS], tt[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) { bet[k] = 0.0; rch[k] = 0; tt[k] = 0; }
+#ifdef GR_SKIP_BRANDES
+    for (int s = wv - 1; s < 0; s += GR_WAVES - 1) {
+#else
+    for (int s = wv - 1; s < n; s += GR_WAVES - 1) {
+#endif
+      int dist[NS];
+      unsigned long long F[NS];
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        dist[k] = (lane + 64 * k == s) ? 0 : -1;
+        F[k] = (s >> 6) == k ? 1ull << (s & 63) : 0ull;
+      }
+      if (lane == (s & 63)) sg[s] = 1.0;
+      int d = 0;
+      while (gr_any<NS>(F)) {      // at most n levels: every level marks at least one new node
+        unsigned long long nf[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+          {
+            const int v = lane + 64 * k;
+            bool hit = false;
+            double acc = 0.0;
+            if (dist[k] < 0) {      // nodes beyond n have empty masks
+#pragma unroll
+              for (int q = 0; q < NS; ++q) {
+                unsigned long long m = (REGS ? inm[k % NM][q % NM] : (v < n ? inmask[4 * v + q] : 0ull)) & F[q];
+                hit = hit || m != 0ull;
+                while (m) {      // two path counts in flight per trip
+                  const int b0 = __builtin_ctzll(m);
+                  m &= m - 1ull;
+                  const double s0 = sg[64 * q + b0];
+                  double s1 = 0.0;
+                  if (m) {
+                    const int b1 = __builtin_ctzll(m);
+                    m &= m - 1ull;
+                    s1 = sg[64 * q + b1];
+                  }
+                  acc += s0;
+                  acc += s1;
+                }
+              }
+            }
+            if (hit) { dist[k] = d + 1; sg[v] = acc; }
+            nf[k] = __ballot(hit);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < NS; ++k) F[k] = nf[k];
+        ++d;
+      }
+      const int dmax = d - 1;      // deepest level reached (the loop ran once more to find it empty)
+#pragma unroll
+      for (int k = 0; k < NS; ++k)
+        if (dist[k] >= 0) { rch[k] += 1; tt[k] += dist[k]; }
+      for (int lev = dmax; lev >= 0; --lev) {
+        unsigned long long nxt[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) nxt[k] = __ballot(dist[k] == lev + 1);
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+          const int v = lane + 64 * k;
+          if (dist[k] == lev) {
+            const double sv = sg[v];
+            double dl = 0.0;
+#pragma unroll
+            for (int q = NS - 1; q >= 0; --q) {
+              unsigned long long m = (REGS ? outm[k % NM][q % NM] : (v < n ? outmask[4 * v + q] : 0ull)) & nxt[q];
+              while (m) {
+                const int b0 = 63 - __builtin_clzll(m);
+                m &= ~(1ull << b0);
+                const double c0 = cf[64 * q + b0];
+                double c1 = 0.0;
+                if (m) {
+                  const int b1 = 63 - __builtin_clzll(m);
+                  m &= ~(1ull << b1);
+                  c1 = cf[64 * q + b1];
+                }
+                dl += sv * c0;
+                dl += sv * c1;
+              }
+            }
+            cf[v] = (1.0 + dl) / sv;
+            if (v != s) bet[k] += dl;
+          }
+        }
+      }
+    }
+    // the wave's sums: betweenness into its own (now idle) path-count row, the integer sums by atomics
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      const int v = lane + 64 * k;
+      if (v < n) {
+        sg[v] = bet[k];
+        if (rch[k]) { atomicAdd(&reach[v], rch[k]); atomicAdd(&tot[v], tt[k]); }
+      }
+    }
 }
 
 extern "C" __global__ __launch_bounds__(GR_THREADS) void s2g_k_graph_features(GraphArgs a) {
@@ -241,6 +436,11 @@ extern "C" __global__ __launch_bounds__(GR_THREADS) void s2g_k_graph_features(Gr
   double* feat = a.feat + (size_t)g * V * 4;
   int* info = a.info + 4 * g;
   for (int i = tid; i < 4 * V; i += GR_THREADS) feat[i] = 0.0;
+#ifdef GR_STAMPS
+  if (tid == 0) gr_stamp_buf = a.work;
+  __syncthreads();
+#endif
+  GR_STAMP(0);
 
   // ---- nodes: the distinct symbols, numbered in ascending order (threads 0..255 = waves 0..3 hold one symbol each)
   if (tid < GR_NMAX) idx[tid] = 0;
@@ -343,9 +543,9 @@ extern "C" __global__ __launch_bounds__(GR_THREADS) void s2g_k_graph_features(Gr
   double* coeff = sigma + GR_WAVES * V;                 // [16][V]
   double* xv = coeff + GR_WAVES * V;                    // [V]
   double* bvec = xv + V;
-  double* lmul = bvec + V;                              // [2][V]
-  double* prow = lmul + 2 * V;
-  double* sol = prow + V;
+  double* lmul = bvec + V;                              // [3][V]
+  double* prow = lmul + 3 * V;                          // [2][V]
+  double* sol = prow + 2 * V;
   int* reach = reinterpret_cast<int*>(sol + V);         // [V]
   int* tot = reach + V;
   int* pos = tot + V;
@@ -353,6 +553,7 @@ extern "C" __global__ __launch_bounds__(GR_THREADS) void s2g_k_graph_features(Gr
   int* perm = rowat + V;
   if (tid < n) { reach[tid] = 0; tot[tid] = 0; }
   __syncthreads();
+  GR_STAMP(1);
 
   int status = 0, iters = 0;
   if (wv == 0) {
@@ -401,92 +602,12 @@ extern "C" __global__ __launch_bounds__(GR_THREADS) void s2g_k_graph_features(Gr
       if (mine[k]) feat[4 * sym[lane + 64 * k] + 3] = xo[k];
   } else {
     // ---- Brandes betweenness + closeness: one breadth-first search per source, a wave per source
-    volatile double* sg = sigma + wv * V;
-    volatile double* cf = coeff + wv * V;
-    const int nk = (n + 63) >> 6;      // node slots in use
-    double bet[4] = {0.0, 0.0, 0.0, 0.0};
-    int rch[4] = {0, 0, 0, 0}, tt[4] = {0, 0, 0, 0};
-#ifdef GR_SKIP_BRANDES
-    for (int s = wv - 1; s < 0; s += GR_WAVES - 1) {
-#else
-    for (int s = wv - 1; s < n; s += GR_WAVES - 1) {
-#endif
-      int dist[4];
-      unsigned long long F[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        dist[k] = (lane + 64 * k == s) ? 0 : -1;
-        F[k] = (s >> 6) == k ? 1ull << (s & 63) : 0ull;
-      }
-      if (lane == (s & 63)) sg[s] = 1.0;
-      int d = 0;
-      while (F[0] | F[1] | F[2] | F[3]) {      // at most n levels: every level marks at least one new node
-        unsigned long long nf[4] = {0ull, 0ull, 0ull, 0ull};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          if (k < nk) {
-            const int v = lane + 64 * k;
-            bool hit = false;
-            double acc = 0.0;
-            if (v < n && dist[k] < 0) {
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                unsigned long long m = inmask[4 * v + q] & F[q];
-                while (m) {
-                  acc += sg[64 * q + __builtin_ctzll(m)];
-                  m &= m - 1ull;
-                  hit = true;
-                }
-              }
-            }
-            if (hit) { dist[k] = d + 1; sg[v] = acc; }
-            nf[k] = __ballot(hit);
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) F[k] = nf[k];
-        ++d;
-      }
-      const int dmax = d - 1;      // deepest level reached (the loop ran once more to find it empty)
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (dist[k] >= 0) { rch[k] += 1; tt[k] += dist[k]; }
-      for (int lev = dmax; lev >= 0; --lev) {
-        unsigned long long nxt[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) nxt[k] = __ballot(dist[k] == lev + 1);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int v = lane + 64 * k;
-          if (k < nk && v < n && dist[k] == lev) {
-            const double sv = sg[v];
-            double dl = 0.0;
-#pragma unroll
-            for (int q = 3; q >= 0; --q) {
-              unsigned long long m = outmask[4 * v + q] & nxt[q];
-              while (m) {
-                const int b = 63 - __builtin_clzll(m);
-                dl += sv * cf[64 * q + b];
-                m &= ~(1ull << b);
-              }
-            }
-            cf[v] = (1.0 + dl) / sv;
-            if (v != s) bet[k] += dl;
-          }
-        }
-      }
-    }
-    // the wave's sums: betweenness into its own (now idle) path-count row, the integer sums by atomics
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int v = lane + 64 * k;
-      if (v < n) {
-        sg[v] = bet[k];
-        if (rch[k]) { atomicAdd(&reach[v], rch[k]); atomicAdd(&tot[v], tt[k]); }
-      }
-    }
+    if (n <= 192) gr_brandes<3>(n, V, lane, wv, inmask, outmask, sigma, coeff, reach, tot);
+    else gr_brandes<4>(n, V, lane, wv, inmask, outmask, sigma, coeff, reach, tot);
   }
+  GR_STAMP(2);
   __syncthreads();
+  GR_STAMP(3);
   if (tid < n) {
     double b = 0.0;
 #pragma unroll
@@ -523,14 +644,16 @@ extern "C" __global__ __launch_bounds__(GR_THREADS) void s2g_k_graph_features(Gr
       }
     }
     static_assert(GR_T == 6, "the calls below enumerate the six tile columns");
+    GR_STAMP(4);
     GrSolve z;
     z.bvec = bvec; z.lmul = lmul; z.prow = prow; z.sol = sol; z.pos = pos; z.rowat = rowat; z.misc = misc; z.n = n; z.V = V;
-    singular = gr_lu_steps<0>(m, fin, z, tx, ty) || gr_lu_steps<1>(m, fin, z, tx, ty) || gr_lu_steps<2>(m, fin, z, tx, ty) ||
-               gr_lu_steps<3>(m, fin, z, tx, ty) || gr_lu_steps<4>(m, fin, z, tx, ty) || gr_lu_steps<5>(m, fin, z, tx, ty);
-    if (!singular) {
-      gr_back_steps<5>(m, z, tx, ty, lane); gr_back_steps<4>(m, z, tx, ty, lane); gr_back_steps<3>(m, z, tx, ty, lane);
-      gr_back_steps<2>(m, z, tx, ty, lane); gr_back_steps<1>(m, z, tx, ty, lane); gr_back_steps<0>(m, z, tx, ty, lane);
-    }
+    singular = gr_gj_steps<0>(m, fin, z, tx, ty, lane) || gr_gj_steps<1>(m, fin, z, tx, ty, lane) ||
+               gr_gj_steps<2>(m, fin, z, tx, ty, lane) || gr_gj_steps<3>(m, fin, z, tx, ty, lane) ||
+               gr_gj_steps<4>(m, fin, z, tx, ty, lane) || gr_gj_steps<5>(m, fin, z, tx, ty, lane);
+    // the system is diagonal now: c_k = b[pivot row of step k] / pivot k (kept in sol by the searchers)
+    GR_STAMP(5);
+    if (!singular && tid < n) sol[tid] = bvec[rowat[tid]] / sol[tid];
+    __syncthreads();
   } else if (want_katz) {
     // ---- Katz, matrix in the global workspace (rows addressed through perm), the right-hand side carried along
     double* M = Mg;
@@ -602,6 +725,7 @@ extern "C" __global__ __launch_bounds__(GR_THREADS) void s2g_k_graph_features(Gr
     }
   }
   if (tid == 0) { info[0] = n; info[1] = status; info[2] = iters; info[3] = colptr[n]; }
+  GR_STAMP(6);
 }
 
 // offset of the solver state inside the shared LDS region: behind the count matrix when both fit (the register
