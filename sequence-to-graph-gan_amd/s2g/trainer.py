@@ -305,6 +305,12 @@ class WGANGPTrainer:
         self.last["g_parts"] = losses
         return losses
 
+    def join_generator(self) -> None:
+        """Order the trainer's stream behind a generator update that generator_step(defer_join=True) left running
+        on the side stream (before anything else reads the generator's parameters or Adam state)."""
+        with self._own_stream():
+            self._join_generator()
+
     def _join_generator(self, waited: bool = False) -> None:
         """Orders the current stream behind a generator update still running on the side stream
         (waited: the stream already waited for it, only the bookkeeping is left)."""

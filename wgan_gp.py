@@ -279,10 +279,25 @@ def train_wgan(generator, discriminator, optimizer_G, optimizer_D, train_dataloa
     device_rng = bool(getattr(opt, "device_rng", False))
     V, Lg = generator.vocab_size, generator.seq_len
 
+    staging = {}      # (shape, dtype) -> [slots, next]: page-locked buffers reused round-robin, an event per slot
+
     def to_dev(t):
         # page-locked staging + an asynchronous copy on the current (the trainer's) stream: the host does not
-        # wait for the step that is still running
-        return t.pin_memory().to(device, non_blocking=True)
+        # wait for the step that is still running.  The buffers are kept (allocating page-locked memory is a slow,
+        # synchronising driver call); a slot is reused once the copy out of it has completed.
+        key = (tuple(t.shape), t.dtype)
+        ring = staging.setdefault(key, [[], 0])
+        if len(ring[0]) < 4:
+            ring[0].append((torch.empty(t.shape, dtype=t.dtype).pin_memory(), torch.cuda.Event()))
+            host, done = ring[0][-1]
+        else:
+            host, done = ring[0][ring[1] % 4]
+            ring[1] += 1
+            done.synchronize()
+        host.copy_(t)
+        out = host.to(device, non_blocking=True)
+        done.record()
+        return out
 
     def upload(batch):
         """Range checks on the host, then the batch as the kernels take it (int32 tokens / lengths)."""
@@ -335,13 +350,15 @@ def train_wgan(generator, discriminator, optimizer_G, optimizer_D, train_dataloa
                 tr.critic_step(cur["tok"], cur["lab"], cur["ln"], cur["wsum"], z=zu.get("z"), U=zu.get("U"), alpha=alpha,
                                next_batch=ahead, gen_next=dict(U=U2) if gen_now else None)
                 if gen_now:
-                    tr.generator_step(U=U2)
+                    # (the output layer's update may still run on the side stream: the next forward waits for it)
+                    tr.generator_step(U=U2, defer_join=True)
                     d_loss, g_loss = tr.losses().tolist()
                     print(
                         "[Epoch %d/%d] [Batch %d/%d] [D loss: %f] [G loss: %f]"
                         % (epoch, opt.epochs, i, n_batches, d_loss, g_loss)
                     )
                     if epoch % 5 == 0:
+                        tr.join_generator()
                         sync_counters()
                         torch.save(generator.state_dict(), f"saved_models/wgan_generator_{epoch}.pth")
                     if epoch % 5 == 0:
@@ -358,6 +375,7 @@ def train_wgan(generator, discriminator, optimizer_G, optimizer_D, train_dataloa
                             print(f"f1 score: {avg_f1_score:.4f}")
                             discriminator.train()
                 cur, zu, i = nxt, zu_next, i + 1
+            tr.join_generator()
     sync_counters()
     _export_adam(optimizer_D, discriminator, tr.mD_named, tr.vD_named, tr.tD)
     _export_adam(optimizer_G, generator, tr.mG_named, tr.vG_named, tr.tG)
