@@ -21,7 +21,7 @@ import sys
 
 
 def per_kernel(d, counter):
-    f = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))[0]
+    f = (glob.glob(os.path.join(d, "*counter_collection.csv")) + glob.glob(os.path.join(d, "*", "*counter_collection.csv")))[0]
     tot, cnt = collections.defaultdict(float), collections.Counter()
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
