@@ -52,8 +52,13 @@ struct GraphLds {
   int idx, sym, misc, red, inmask, outmask, invs, colptr, eval, esrc, uni, total;
 };
 __host__ __device__ inline int graph_cnt_bytes(int V) { return (2 * V * V + 4 + 15) & ~15; }
-// sigma[16][V], coeff[16][V], x[V], bvec[V], lmul[3][V], prow[2][V], sol[V] doubles; reach, tot, pos, rowat, perm ints
-__host__ __device__ inline int graph_state_bytes(int V) { return (8 * (32 * V + 8 * V) + 4 * 5 * V + 15) & ~15; }
+// sigma[16][V], coeff[16][V], x[V] doubles, reach[V], tot[V] ints; solver arrays of S = max(V, GR_LU_NMAX) entries:
+// bvec, lmul[3], prow[2], sol doubles, pos, rowat, perm ints
+__host__ __device__ inline int graph_solver_stride(int V) { return V > GR_LU_NMAX ? V : GR_LU_NMAX; }
+__host__ __device__ inline int graph_state_bytes(int V) {
+  const int S = graph_solver_stride(V);
+  return (8 * (33 * V + 7 * S) + 4 * (2 * V + 3 * S) + 15) & ~15;
+}
 __host__ __device__ inline GraphLds graph_lds_layout(int V, int ecap, int state_off) {
   GraphLds o;
   int p = 0;
@@ -116,7 +121,7 @@ struct GrSolve {      // LDS state of the Katz solver
   double *bvec, *lmul, *prow, *sol;
   int *pos, *rowat;
   volatile int* misc;
-  int n, V;
+  int n, S;      // nodes; entries per solver array (>= GR_LU_NMAX)
 };
 
 template <int CTRL>
@@ -144,7 +149,7 @@ template <int KJ>
 __device__ __forceinline__ bool gr_gj_steps(double (&m)[GR_T][GR_T], unsigned& fin, const GrSolve& z, int tx, int ty,
                                             int lane) {
   // fused multiply-adds are allowed here (LAPACK's kernels use them too); the other phases keep separate roundings
-  const int n = z.n, V = z.V;
+  const int n = z.n, V = z.S;      // stride of the multiplier / pivot-row buffers
   for (int kc = 0; kc < 32; ++kc) {
     const int ks = 32 * KJ + kc;
     if (ks >= n) break;
@@ -162,52 +167,56 @@ __device__ __forceinline__ bool gr_gj_steps(double (&m)[GR_T][GR_T], unsigned& f
     double* lm0 = z.lmul + (ks % 3) * V;                   // multipliers of step ks (written here)
     const double* pr2 = z.prow + (ks & 1) * V;             // pivot row of step ks - 2
     double* pr1 = z.prow + ((ks + 1) & 1) * V;             // pivot row of step ks - 1 (written here)
+    // LDS loads below are UNCONDITIONAL and the conditions are applied to the loaded values: a load under a
+    // per-lane condition becomes a branch with its own wait for LDS inside, i.e. one full LDS round trip per use
+    // instead of one per batch (this section was 5 000 cycles per step that way).  The solver's arrays hold
+    // GR_LU_NMAX entries whatever n is, so row 32 i + ty is always inside them and its address is one base
+    // register per array plus an immediate offset.
+    bool rok[GR_T];
+#pragma unroll
+    for (int i = 0; i < GR_T; ++i) rok[i] = 32 * i + ty < n;
     if (tx == kc) {      // a half-wave: the owners of column ks; the other waves wait for what it publishes
       __builtin_amdgcn_s_setprio(3);
-      // every LDS operand of the search is fetched up front (one round trip instead of one per use)
-      double l1[GR_T];
+      double l2[GR_T], l1[GR_T];
       int ps[GR_T];
 #pragma unroll
-      for (int i = 0; i < GR_T; ++i) {
-        const int r = 32 * i + ty;
-        const bool ok = r < n;
-        l1[i] = (ks >= 1 && ok) ? lm1[r] : 0.0;
-        ps[i] = ok ? z.pos[r] : 0;
-      }
-      const double p2 = ks >= 2 ? pr2[ks] : 0.0;
+      for (int i = 0; i < GR_T; ++i) { l2[i] = lm2[32 * i + ty]; l1[i] = lm1[32 * i + ty]; ps[i] = z.pos[32 * i + ty]; }
+      double p2 = pr2[ks];
       const int rk = z.rowat[ks];
+      p2 = ks >= 2 ? p2 : 0.0;
 #pragma unroll
       for (int i = 0; i < GR_T; ++i) {
-        const int r = 32 * i + ty;
-        m[i][KJ] -= ((ks >= 2 && r < n) ? lm2[r] : 0.0) * p2;
+        l2[i] = (ks >= 2 && rok[i]) ? l2[i] : 0.0;      // (a stale buffer may hold anything, NaN included)
+        l1[i] = (ks >= 1 && rok[i]) ? l1[i] : 0.0;
+        m[i][KJ] -= l2[i] * p2;
       }
-      if (ks >= 1) {
+      {
         double col[GR_T];
 #pragma unroll
         for (int i = 0; i < GR_T; ++i) col[i] = m[i][KJ];
-        const double p1 = __shfl(gr_pick(col, pkp >> 5), (lane & 32) + (pkp & 31));
+        double p1 = __shfl(gr_pick(col, pkp >> 5), (lane & 32) + (pkp & 31));
+        p1 = ks >= 1 ? p1 : 0.0;
 #pragma unroll
         for (int i = 0; i < GR_T; ++i) m[i][KJ] -= l1[i] * p1;
       }
       // pivot: largest magnitude among the unfinished rows, the row LAPACK's row order lists first on ties
-      double bv = -1.0, bs = 0.0;
-      int key = 0x7fffffff;
+      double gv = -1.0, bs = 0.0;
+      int gk = 0x7fffffff;
 #pragma unroll
       for (int i = 0; i < GR_T; ++i) {
-        if (!((fin >> i) & 1u)) {
-          const double av = fabs(m[i][KJ]);
-          const int kk = (ps[i] << 8) | (32 * i + ty);
-          if (av > bv || (av == bv && kk < key)) { bv = av; key = kk; bs = m[i][KJ]; }
-        }
+        const double av = ((fin >> i) & 1u) ? -2.0 : fabs(m[i][KJ]);
+        const int kk = (ps[i] << 8) | (32 * i + ty);
+        const bool take = av > gv || (av == gv && kk < gk);
+        gv = take ? av : gv;
+        gk = take ? kk : gk;
+        bs = take ? m[i][KJ] : bs;
       }
-      double gv = bv;
-      int gk = key;
       gr_better(gv, gk, gr_dpp_d<DPP_QUAD(1, 0, 3, 2)>(gv), gr_dpp_i<DPP_QUAD(1, 0, 3, 2)>(gk));
       gr_better(gv, gk, gr_dpp_d<DPP_QUAD(2, 3, 0, 1)>(gv), gr_dpp_i<DPP_QUAD(2, 3, 0, 1)>(gk));
       gr_better(gv, gk, gr_dpp_d<DPP_ROW_HALF_MIRROR>(gv), gr_dpp_i<DPP_ROW_HALF_MIRROR>(gk));
       gr_better(gv, gk, gr_dpp_d<DPP_ROW_MIRROR>(gv), gr_dpp_i<DPP_ROW_MIRROR>(gk));
       gr_better(gv, gk, __shfl_xor(gv, 16), __shfl_xor(gk, 16));
-      if (!(gv > 0.0)) {
+      if (!(gv > 0.0)) {      // uniform over the half-wave
         if (ty == 0) z.misc[12] = 1;
       } else {
         const int br = gk & 255;
@@ -215,16 +224,16 @@ __device__ __forceinline__ bool gr_gj_steps(double (&m)[GR_T][GR_T], unsigned& f
         const double piv = __shfl(bs, wl);
         double bo[GR_T];      // right-hand side of this thread's rows: all reads first, then all writes
 #pragma unroll
-        for (int i = 0; i < GR_T; ++i) { const int r = 32 * i + ty; bo[i] = r < n ? z.bvec[r] : 0.0; }
+        for (int i = 0; i < GR_T; ++i) bo[i] = z.bvec[32 * i + ty];
         const double bk = z.bvec[br];
         const double rinv = 1.0 / piv;
 #pragma unroll
         for (int i = 0; i < GR_T; ++i) {
           const int r = 32 * i + ty;
-          if (r < n) {
-            const double l = (r != br) ? m[i][KJ] * rinv : 0.0;
+          const double l = (r != br) ? m[i][KJ] * rinv : 0.0;
+          if (rok[i]) {      // stores only: nothing waits inside these branches
             lm0[r] = l;
-            if (r != br) z.bvec[r] = bo[i] - l * bk;
+            z.bvec[r] = bo[i] - l * bk;      // (l = 0 on the pivot row: its entry is rewritten unchanged)
           }
         }
         if (ty == 0) {
@@ -242,9 +251,13 @@ __device__ __forceinline__ bool gr_gj_steps(double (&m)[GR_T][GR_T], unsigned& f
     if (ks >= 2) {      // trailing update ks - 2 on the columns beyond ks: tile columns below KJ are finished
       double l2[GR_T], p[GR_T];      // (read here, not before the search: the tile leaves few registers to hold them)
 #pragma unroll
-      for (int i = 0; i < GR_T; ++i) { const int r = 32 * i + ty; l2[i] = r < n ? lm2[r] : 0.0; }
+      for (int i = 0; i < GR_T; ++i) l2[i] = lm2[32 * i + ty];
 #pragma unroll
-      for (int j = KJ; j < GR_T; ++j) { const int c = 32 * j + tx; p[j] = (c < n && c > ks) ? pr2[c] : 0.0; }
+      for (int j = KJ; j < GR_T; ++j) p[j] = pr2[32 * j + tx];
+#pragma unroll
+      for (int i = 0; i < GR_T; ++i) l2[i] = rok[i] ? l2[i] : 0.0;
+#pragma unroll
+      for (int j = KJ; j < GR_T; ++j) { const int c = 32 * j + tx; p[j] = (c < n && c > ks) ? p[j] : 0.0; }
 #pragma unroll
       for (int i = 0; i < GR_T; ++i)
 #pragma unroll
@@ -541,16 +554,17 @@ extern "C" __global__ __launch_bounds__(GR_THREADS) void s2g_k_graph_features(Gr
   char* st = uni + a.state_off;
   double* sigma = reinterpret_cast<double*>(st);        // [16][V]
   double* coeff = sigma + GR_WAVES * V;                 // [16][V]
+  const int S = graph_solver_stride(V);
   double* xv = coeff + GR_WAVES * V;                    // [V]
-  double* bvec = xv + V;
-  double* lmul = bvec + V;                              // [3][V]
-  double* prow = lmul + 3 * V;                          // [2][V]
-  double* sol = prow + 2 * V;
-  int* reach = reinterpret_cast<int*>(sol + V);         // [V]
+  double* bvec = xv + V;                                // [S]
+  double* lmul = bvec + S;                              // [3][S]
+  double* prow = lmul + 3 * S;                          // [2][S]
+  double* sol = prow + 2 * S;                           // [S]
+  int* reach = reinterpret_cast<int*>(sol + S);         // [V]
   int* tot = reach + V;
-  int* pos = tot + V;
-  int* rowat = pos + V;
-  int* perm = rowat + V;
+  int* pos = tot + V;                                   // [S]
+  int* rowat = pos + S;
+  int* perm = rowat + S;
   if (tid < n) { reach[tid] = 0; tot[tid] = 0; }
   __syncthreads();
   GR_STAMP(1);
@@ -646,7 +660,7 @@ extern "C" __global__ __launch_bounds__(GR_THREADS) void s2g_k_graph_features(Gr
     static_assert(GR_T == 6, "the calls below enumerate the six tile columns");
     GR_STAMP(4);
     GrSolve z;
-    z.bvec = bvec; z.lmul = lmul; z.prow = prow; z.sol = sol; z.pos = pos; z.rowat = rowat; z.misc = misc; z.n = n; z.V = V;
+    z.bvec = bvec; z.lmul = lmul; z.prow = prow; z.sol = sol; z.pos = pos; z.rowat = rowat; z.misc = misc; z.n = n; z.S = S;
     singular = gr_gj_steps<0>(m, fin, z, tx, ty, lane) || gr_gj_steps<1>(m, fin, z, tx, ty, lane) ||
                gr_gj_steps<2>(m, fin, z, tx, ty, lane) || gr_gj_steps<3>(m, fin, z, tx, ty, lane) ||
                gr_gj_steps<4>(m, fin, z, tx, ty, lane) || gr_gj_steps<5>(m, fin, z, tx, ty, lane);

@@ -31,13 +31,16 @@ def _convergence_error(iterations):
 
 
 def graph_features(tokens: torch.Tensor, lengths: torch.Tensor | None = None, vocab: int = 175):
-    """tokens int32 [N, L] on the device (symbol ids in [0, vocab)), lengths int32 [N] or None ->
+    """tokens int32 (or int64, as Generator.sample_tokens returns them) [N, L] on the device (symbol ids in
+    [0, vocab)), lengths int32 [N] or None ->
     (feat float64 [N, vocab, 4] = katz, betweenness, closeness, pagerank by symbol id; info int32 [N, 4] = nodes,
     status, pagerank iterations, distinct edges).  Stays on the device and on the current stream."""
     if not tokens.is_cuda:
         raise S2GError("graph_features needs device tensors: the HIP kernel is the only implementation")
+    if tokens.dtype == torch.int64:
+        tokens = tokens.to(torch.int32)
     if tokens.dtype != torch.int32 or tokens.dim() != 2 or not tokens.is_contiguous():
-        raise S2GError("tokens must be a contiguous int32 [N, L] tensor")
+        raise S2GError("tokens must be a contiguous int32 (or int64) [N, L] tensor")
     N, L = tokens.shape
     if not 0 < vocab <= MAX_NODES:
         raise S2GError(f"graph_features supports at most {MAX_NODES} distinct symbols, got vocab={vocab}")

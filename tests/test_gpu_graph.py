@@ -101,3 +101,24 @@ def test_batches_against_cpu_restatement(skew, V, L, N):
         np.testing.assert_allclose(got[:, 0], f[:, 0], rtol=1e-6, atol=1e-9, err_msg=f"row {r} katz")
         edges = len({(a, b) for a, b in zip(seq[:-1], seq[1:])})
         assert info[r, 3] == edges
+
+
+def test_generated_sequences_to_graph_features_on_the_device():
+    """The consumer pipeline without a trip to the host: Generator.sample_tokens (the fused decode of
+    generate_fake_data.py:64-66) -> graph_features (graph_encoder.py:57-133), checked against the CPU restatement
+    on the same tokens."""
+    import wgan_gp as W
+    from oracle import graph_cpu
+    from s2g import graph
+    dev = torch.device("cuda:0")
+    gen = W.Generator(175, 2, seq_len=120).to(dev).eval()
+    g = common.gen(99)
+    noise = torch.randn(12, 100, generator=g).to(dev)
+    labels = torch.randint(0, 2, (12,), generator=g).to(dev)
+    tokens = gen.sample_tokens(noise, labels)                      # int64 [12, 120], device
+    feat, info = graph.graph_features(tokens, None, vocab=175)
+    tok, feat, info = tokens.cpu(), feat.cpu().numpy(), info.cpu().numpy()
+    for r in range(tok.shape[0]):
+        f, unique, _ = graph_cpu.features(tok[r].tolist())
+        assert info[r, 0] == len(unique) and info[r, 1] == 0
+        np.testing.assert_allclose(feat[r][np.array(unique)], f, rtol=1e-9, atol=1e-13)
