@@ -616,7 +616,10 @@ extern "C" __global__ __launch_bounds__(GR_THREADS) void s2g_k_graph_features(Gr
       if (mine[k]) feat[4 * sym[lane + 64 * k] + 3] = xo[k];
   } else {
     // ---- Brandes betweenness + closeness: one breadth-first search per source, a wave per source
-    if (n <= 192) gr_brandes<3>(n, V, lane, wv, inmask, outmask, sigma, coeff, reach, tot);
+    // (one node slot and one mask word per 64 nodes: small graphs do not pay for empty slots)
+    if (n <= 64) gr_brandes<1>(n, V, lane, wv, inmask, outmask, sigma, coeff, reach, tot);
+    else if (n <= 128) gr_brandes<2>(n, V, lane, wv, inmask, outmask, sigma, coeff, reach, tot);
+    else if (n <= 192) gr_brandes<3>(n, V, lane, wv, inmask, outmask, sigma, coeff, reach, tot);
     else gr_brandes<4>(n, V, lane, wv, inmask, outmask, sigma, coeff, reach, tot);
   }
   GR_STAMP(2);
