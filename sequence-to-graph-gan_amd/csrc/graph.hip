@@ -328,7 +328,7 @@ __device__ __forceinline__ void gr_brandes(int n, int V, int lane, int wv, const
     int rch[NS], tt[NS];
 #pragma unroll
     for (int k = 0; k < NS; ++k) { bet[k] = 0.0; rch[k] = 0; tt[k] = 0; }
-#ifdef GR_SKIP_BRANDES
+#ifdef GR_SKIP_BRANDES      // timing builds only: no traversal (zero betweenness / closeness)
     for (int s = wv - 1; s < 0; s += GR_WAVES - 1) {
 #else
     for (int s = wv - 1; s < n; s += GR_WAVES - 1) {
@@ -537,7 +537,7 @@ extern "C" __global__ __launch_bounds__(GR_THREADS) void s2g_k_graph_features(Gr
       }
     }
   }
-#ifdef GR_SKIP_KATZ
+#ifdef GR_SKIP_KATZ         // timing builds only: no solve (zero Katz column)
   const bool want_katz = false;
 #else
   const bool want_katz = n > 2;
