@@ -23,7 +23,6 @@ if _PKG not in sys.path:
 
 from config import get_args  # noqa: E402
 from s2g import data as s2g_data  # noqa: E402
-from s2g import ops  # noqa: E402
 from s2g.critic import CriticEngine  # noqa: E402
 from s2g.generator import GeneratorEngine  # noqa: E402
 from s2g.lib import S2GError  # noqa: E402
