@@ -694,12 +694,12 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         if prefetch is not None and eng.stream_g is not None:
             # The hook's work (not part of the join) goes to the masked stream of its own.  Its light part
             # starts right away; its heavy, HBM-bound part (the generator's output layer, 183 MB of weights)
-            # waits for sweep C: beside the phase-0 products it slows them past the end of sweep C (308
-            # against 217 us), while started with sweep D it is through before the last products begin,
-            # which then run alone (65 against 113 us when it only started after the phase-1 products;
-            # those take 109 instead of 50 us beside it, hidden under sweep D's 270).
+            # waits for the phase-1 products (`join`): beside the phase-0 products it slows them past the end of
+            # sweep C (308 against 217 us); beside the phase-1 products both crawl (134 + 144 us under sweep D
+            # instead of 55 + 80 one after the other) -- the step time is the same either way, but one after the
+            # other they finish well before sweep D does and leave the last products alone on the chip.
             with torch.cuda.stream(eng.stream_g):
-                prefetch(lambda: eng.stream_g.wait_event(after_c))
+                prefetch(lambda: eng.stream_g.wait_event(join))
         if idle is not None and own:
             with torch.cuda.stream(stream_c):      # free while the sweeps run on the caller's stream
                 stream_c.wait_event(fork)
