@@ -38,3 +38,25 @@ def test_check_batch_rejects_labels(labels):
 def test_check_batch_rejects_lengths(lengths):
     with pytest.raises(S2GError, match="lengths"):
         check_batch(lengths=torch.tensor(lengths), T=4)
+
+
+def test_graph_features_rejects_what_the_kernel_cannot_take():
+    """Host-side checks of the sequence -> graph wrapper (no GPU needed): CPU tensors, dtypes, size limits; the C
+    entry point returns -1 / -3 before any launch."""
+    import pytest
+    from s2g import graph, lib
+    from s2g.lib import S2GError
+    with pytest.raises(S2GError):
+        graph.graph_features(torch.zeros(2, 8, dtype=torch.int32), None, vocab=16)          # not on the device
+    l = lib.load()
+    assert l.s2g_graph_features(None, None, 1, 8, 16, None, None, None, 0, None) == -1
+    assert l.s2g_graph_features_workspace(3, 175) == 3 * 175 * 175 * 8
+    assert l.s2g_graph_features_workspace(1, 300) == -1                                     # more than 256 symbols
+    import graph_encoder
+    enc = graph_encoder.GraphEncoder(device="cpu")
+    with pytest.raises(ValueError, match="Sequence is empty."):
+        enc.encode([])
+    with pytest.raises(S2GError):
+        enc.encode(list(range(300)))                                                        # 300 distinct symbols
+    enc.build_vocabulary(["open", "read", "open"])
+    assert enc.syscall_vocabs == {i: i for i in range(300)} | {"open": 300, "read": 301}    # grows in first-seen order
