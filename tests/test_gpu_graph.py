@@ -122,3 +122,24 @@ def test_generated_sequences_to_graph_features_on_the_device():
         f, unique, _ = graph_cpu.features(tok[r].tolist())
         assert info[r, 0] == len(unique) and info[r, 1] == 0
         np.testing.assert_allclose(feat[r][np.array(unique)], f, rtol=1e-9, atol=1e-13)
+
+
+def test_degenerate_lengths_and_out_of_range_symbols():
+    """Lengths 0 and 1 give no graph (zero features, as the reference's singleton branch assigns them,
+    graph_encoder.py:112-120); lengths beyond L and symbols outside [0, V) are clamped, never indexed with."""
+    from oracle import graph_cpu
+    from s2g import graph
+    V, L = 20, 16
+    tok = torch.tensor([[3] * L, [5] + [0] * (L - 1), list(range(L)), [-7, 99] + [4, 9] * 7], dtype=torch.int32)
+    lengths = torch.tensor([0, 1, 1000, L], dtype=torch.int32)
+    feat, info = graph.graph_features(tok.cuda(), lengths.cuda(), vocab=V)
+    feat, info = feat.cpu().numpy(), info.cpu().numpy()
+    assert info[0].tolist() == [0, 0, 0, 0] and info[1].tolist() == [1, 0, 0, 0]
+    assert float(np.abs(feat[:2]).max()) == 0.0
+    f, unique, _ = graph_cpu.features(list(range(L)))                     # length clamped to L
+    assert info[2, 0] == L
+    np.testing.assert_allclose(feat[2][np.array(unique)], f, rtol=1e-9, atol=1e-13)
+    clamped = [0, V - 1] + [4, 9] * 7                                      # what the kernel makes of -7 and 99
+    f, unique, _ = graph_cpu.features(clamped)
+    assert info[3, 0] == len(unique)
+    np.testing.assert_allclose(feat[3][np.array(unique)], f, rtol=1e-9, atol=1e-13)
