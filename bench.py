@@ -293,8 +293,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
     # S2G_REHEARSE=1: every rank on GPU 0 with the gloo backend -- exercises the multi-rank code path
     # on a one-GPU machine (its number is meaningless; RCCL needs one GPU per rank)
+    # S2G_REHEARSE=rccl1: ONE rank, but with an RCCL process group and the multi-rank code path (split
+    # BatchNorm kernels, three-launch critic update, every all-reduce issued on RCCL's stream)
     rehearse = os.environ.get("S2G_REHEARSE") == "1"
-    comm, rank, local, world = init_from_env("gloo" if rehearse else "nccl")
+    rccl1 = os.environ.get("S2G_REHEARSE") == "rccl1"
+    comm, rank, local, world = init_from_env("gloo" if rehearse else "nccl", force_split=rccl1)
     if world != max(a.gpus, 1):
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run")
     if rehearse:

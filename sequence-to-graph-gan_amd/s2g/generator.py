@@ -32,6 +32,7 @@ def generator_shapes(vocab: int, seq_len: int, n_classes: int = 2):
 
 class NoComm:
     world = 1
+    split = False          # True: take the multi-rank code paths (all-reduces between the split kernels)
 
     def allreduce(self, t: torch.Tensor) -> None:  # sum over ranks, in place
         return
@@ -68,7 +69,7 @@ class GeneratorEngine:
         invstd = torch.empty(F_, device=self.device) if training else None
         stats = None
         n_global = float(B * self.comm.world)
-        if training and self.comm.world == 1:
+        if training and not self.comm.split:
             # one process: batch statistics need no all-reduce, statistics + normalise in one launch
             call("s2g_bn_lrelu_fwd_fused", ptr(pre), ptr(p[name + ".weight"]), ptr(p[name + ".bias"]),
                  ptr(self.buffers[name + ".running_mean"]), ptr(self.buffers[name + ".running_var"]), BN_EPS,
@@ -177,7 +178,7 @@ class GeneratorEngine:
     # ------------------------------------------------------------------ backward
     def _bn_bwd(self, a, da, xhat, inv, name, B, F_):
         g = self.grads.views
-        if self.comm.world == 1:
+        if not self.comm.split:
             dpre = torch.empty_like(da)
             call("s2g_bn_lrelu_bwd_fused", ptr(a), ptr(da), ptr(xhat), ptr(self.params.views[name + ".weight"]),
                  ptr(inv), ptr(g[name + ".weight"]), ptr(g[name + ".bias"]), ptr(dpre), B, F_, stream_ptr())

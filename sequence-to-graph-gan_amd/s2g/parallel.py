@@ -22,14 +22,18 @@ import torch.distributed as dist
 
 
 class DistComm:
-    def __init__(self, group=None):
+    def __init__(self, group=None, force_split: bool = False):
+        """force_split: take the multi-rank code paths (split BatchNorm kernels, three-launch critic update,
+        every all-reduce issued) even in a group of one rank: a rehearsal of the RCCL calls and of their
+        stream on a one-GPU machine."""
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        self.split = self.world > 1 or force_split
 
     def allreduce(self, t: torch.Tensor) -> None:
         """Sum over the ranks, in place, ordered behind the work enqueued on the current stream."""
-        if self.world > 1:
+        if self.split:
             if t.is_cuda and dist.get_backend(self.group) == "gloo":
                 # rehearsal on one GPU: gloo stages device tensors through the host and its own wait for a
                 # busy stream can hang with several processes on one card; drain the GPU first
@@ -41,13 +45,14 @@ class DistComm:
             dist.barrier(group=self.group)
 
 
-def init_from_env(backend: str = "nccl"):
+def init_from_env(backend: str = "nccl", force_split: bool = False):
     """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torch.distributed.run).
-    Returns (comm or None, rank, local_rank, world)."""
+    Returns (comm or None, rank, local_rank, world).  force_split: build a process group and a
+    DistComm(force_split=True) even for one rank."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world <= 1:
+    if world <= 1 and not force_split:
         return None, 0, local, 1
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
@@ -57,7 +62,7 @@ def init_from_env(backend: str = "nccl"):
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    return DistComm(), rank, local, world
+    return DistComm(force_split=force_split), rank, local, world
 
 
 def shard(n_global: int, rank: int, world: int):
@@ -72,7 +77,7 @@ def global_wsum(labels_cpu: torch.Tensor, comm, device=None) -> float:
     """Global sum of the class weights [1,2] over all ranks' labels (wgan_gp.py:267)."""
     n1 = int((labels_cpu == 1).sum())
     w = 1.0 * (labels_cpu.numel() - n1) + 2.0 * n1
-    if comm is None or comm.world == 1:
+    if comm is None or not comm.split:
         return w
     t = torch.tensor([w], dtype=torch.float64, device=device or "cpu")
     comm.allreduce(t)

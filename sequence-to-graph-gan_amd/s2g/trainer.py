@@ -46,7 +46,7 @@ class WGANGPTrainer:
         self.G = gen_engine or GeneratorEngine(vocab, gen_seq_len, self.device, comm=self.comm)
         self.G.comm = self.comm
         self.D = critic_engine or CriticEngine(vocab, self.device)
-        self.D.reserve_comm_stream = self.comm.world > 1
+        self.D.reserve_comm_stream = self.comm.split
         if dtype not in ("f32", "bf16"):
             raise S2GError("dtype must be 'f32' (exact fp32 MFMA everywhere) or 'bf16' (bf16 operands in the critic's "
                            "input-layer products, fp32 accumulation and fp32 recurrence)")
@@ -216,7 +216,7 @@ class WGANGPTrainer:
         else:
             idle = None
         # one process: the final slab reduction, Adam and the weight repack run as one launch
-        fused = update and self.fuse_update and self.comm.world == 1
+        fused = update and self.fuse_update and not self.comm.split
         losses, pen = critic_iteration(self.D, tokens, lengths, labels, fake, alpha.reshape(-1).contiguous(),
                                        self.lambda_gp, n_global, 1.0 / wsum, mask, CLASS_W, prefetch=prefetch,
                                        idle=idle, desc=desc, defer_reduce=fused)
