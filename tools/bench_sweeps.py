@@ -60,38 +60,42 @@ def main():
         if a.startswith("--T="):
             T = int(a[4:])
     use_mask = "--mask" in sys.argv
+    S = T                                   # workspace rows per sequence (--stride=N: padded, N >= T)
+    for a in sys.argv[1:]:
+        if a.startswith("--stride="):
+            S = int(a[9:])
     eng = CriticEngine(V, dev)
     eng.load(common.critic_params(802))
-    ws = eng.workspace(3 * B, T, B)
+    ws = eng.workspace(3 * B, S, B)
     P = torch.randn(B * T, 200, device=dev) * 0.3
     tok = torch.randint(0, V, (B, T), device=dev, dtype=torch.int32)
     mask = None
     if use_mask:
-        mask = (torch.rand(3 * B * T, 52, device=dev) > 0.3).float() / 0.7
+        mask = (torch.rand(3 * B * S, 52, device=dev) > 0.3).float() / 0.7
     ent = []
     for b in range(B):
-        ent.append(dict(len=T, tok_off=b * T, ca=1.0, cp=0.0, ws_row=b * T, mask_off=b * T if use_mask else -1))
+        ent.append(dict(len=T, tok_off=b * T, ca=1.0, cp=0.0, ws_row=b * S, mask_off=b * S if use_mask else -1))
     for b in range(B):
-        ent.append(dict(len=T, p_off=b * T, p_len=T, ca=0.0, cp=1.0, ws_row=(B + b) * T,
-                        mask_off=(B + b) * T if use_mask else -1))
+        ent.append(dict(len=T, p_off=b * T, p_len=T, ca=0.0, cp=1.0, ws_row=(B + b) * S,
+                        mask_off=(B + b) * S if use_mask else -1))
     for b in range(B):
-        ent.append(dict(len=T, tok_off=b * T, p_off=b * T, p_len=T, ca=0.3, cp=0.7, ws_row=(2 * B + b) * T,
-                        mask_off=(2 * B + b) * T if use_mask else -1))
+        ent.append(dict(len=T, tok_off=b * T, p_off=b * T, p_len=T, ca=0.3, cp=0.7, ws_row=(2 * B + b) * S,
+                        mask_off=(2 * B + b) * S if use_mask else -1))
     for b in range(B):
-        ent.append(dict(len=T, tok_off=b * T, p_off=b * T, p_len=T, ca=0.3, cp=0.7, ws_row=b * T,
-                        mask_off=b * T if use_mask else -1))
+        ent.append(dict(len=T, tok_off=b * T, p_off=b * T, p_len=T, ca=0.3, cp=0.7, ws_row=b * S,
+                        mask_off=b * S if use_mask else -1))
     desc = make_desc(ent, dev)
     ws["dhT"].normal_()
     ws["Pv"].normal_()
-    r0 = 2 * B * T
+    r0 = 2 * B * S
     mrel = ptr(mask, r0 * 52) if mask is not None else None
     res = {}
     res["fwd_192"] = timeit(lambda: eng.sweep_fwd(ws, ptr(desc), 3 * B, T, tok, P, mask))
     res["fwd_64"] = timeit(lambda: eng.sweep_fwd(ws, ptr(desc), B, T, tok, P, mask))
-    res["bwd_192"] = timeit(lambda: eng.sweep_bwd(ws, ptr(desc), 3 * B, T, mask, adj_seq0=2 * B))
-    res["bwd_64"] = timeit(lambda: eng.sweep_bwd(ws, ptr(desc), B, T, mask))
+    res["bwd_192"] = timeit(lambda: eng.sweep_bwd(ws, ptr(desc), 3 * B, S, mask, adj_seq0=2 * B))
+    res["bwd_64"] = timeit(lambda: eng.sweep_bwd(ws, ptr(desc), B, S, mask))
     res["tangent_64"] = timeit(lambda: eng.sweep_tangent(ws, ptr(desc, 3 * B * 8), B, mrel, r0))
-    res["bwd2_64"] = timeit(lambda: eng.sweep_bwd2(ws, ptr(desc, 3 * B * 8), B, T, mrel, r0))
+    res["bwd2_64"] = timeit(lambda: eng.sweep_bwd2(ws, ptr(desc, 3 * B * 8), B, S, mrel, r0))
     if "--tall" in sys.argv:
         from s2g import ops
         fake = torch.rand(B * T, V, device=dev)
