@@ -92,6 +92,23 @@ int s2g_gemm_tall_bf16(const float* A, long lda, const float* B, long ldb, float
  * CU; more workgroups than that would run in two rounds), 0 = all CUs of the device. */
 int s2g_linear_small_batch(const float* W, const float* x, const float* bias, float* y, int n_out, int batch, int K,
                            int max_workgroups, void* stream);
+/* Weight gradient of the same layer fused with its Adam step: what loss.backward() leaves in
+ * model[8].weight.grad (wgan_gp.py:341, dW[n_out, K] = dy[batch, n_out]^T a[batch, K]) and
+ * optimizer_G.step() (wgan_gp.py:342, torch.optim.Adam without weight decay / amsgrad) then does to W and
+ * its moments m, v, in ONE pass over W, m and v; the arithmetic per element is s2g_adam's.  grad_w (optional,
+ * may be NULL) also receives dW.  batch <= 64, K = 256 or 512, W / m / v / grad_w 16-byte aligned;
+ * step = 1-based count of this update; max_workgroups as for s2g_linear_small_batch.  Single process only:
+ * with several ranks the gradient has to be all-reduced before Adam sees it. */
+int s2g_linear_wgrad_adam(const float* dy, const float* a, float* W, float* m, float* v, float* grad_w, int n_out,
+                          int batch, int K, float lr, float b1, float b2, float eps, int step, int max_workgroups,
+                          void* stream);
+/* Weight and bias gradients of up to four small nn.Linear layers in one launch (the generator's
+ * 100 -> 128 -> 256 -> 512 stack, wgan_gp.py:147-156; what loss.backward(), wgan_gp.py:341, leaves in their
+ * .grad): for job j, dW[j][n_out, n_in] = dy[j][batch, n_out]^T x[j][batch, n_in] and (db[j] not NULL)
+ * db[j][n_out] = column sums of dy[j].  The arrays are HOST arrays of n_jobs (1..4) entries; n_in % 4 == 0,
+ * x[j] / dW[j] 16-byte aligned, batch <= 4096. */
+int s2g_small_linear_grads(int n_jobs, const float* const* dy, const float* const* x, float* const* dW,
+                           float* const* db, const int* n_out, const int* n_in, int batch, void* stream);
 /* Generator output layer + Gumbel-softmax + argmax in one kernel: what generate_fake_data.py:64-66 computes
  * as generator(noise, labels, tau, hard).argmax(-1) from the last hidden activations x [batch, K]
  * (wgan_gp.py:159, 169-171): tokens[b][t] = argmax_v (x[b] . W[t V + v] + bias[t V + v] + gumbel(u[b][t][v])),

@@ -10,6 +10,7 @@
 #include "attention.hip"
 #include "lstm64.hip"
 #include "graph.hip"
+#include "linear_adam.hip"
 #include <math.h>
 #include <mutex>
 
@@ -109,6 +110,34 @@ int s2g_linear_small_batch(const float* W, const float* x, const float* bias, fl
   if ((((uintptr_t)W) | ((uintptr_t)y) | ((uintptr_t)bias)) & 15) return -1;
   if (max_workgroups < 0) return -1;
   return s2g_launch_linear_wstream(W, x, bias, y, n_out, batch, K, max_workgroups, ST(stream));
+}
+
+int s2g_linear_wgrad_adam(const float* dy, const float* a, float* W, float* m, float* v, float* grad_w, int n_out,
+                          int batch, int K, float lr, float b1, float b2, float eps, int step, int max_workgroups,
+                          void* stream) {
+  if (!dy || !a || !W || !m || !v || n_out <= 0 || batch <= 0 || batch > 64 || K <= 0 || step < 1) return -1;
+  if ((K & 255) || K > 512 || max_workgroups < 0) return -1;                // a workgroup owns 256 columns
+  if ((((uintptr_t)W) | ((uintptr_t)m) | ((uintptr_t)v) | ((uintptr_t)grad_w)) & 15) return -1;
+  const double bc1 = 1.0 - pow((double)b1, (double)step);                   // as s2g_adam
+  const double bc2 = 1.0 - pow((double)b2, (double)step);
+  return s2g_launch_linear_wgrad_adam(dy, a, W, m, v, grad_w, n_out, batch, K, b1, b2, eps, (float)((double)lr / bc1),
+                                      (float)(1.0 / sqrt(bc2)), max_workgroups, ST(stream));
+}
+
+int s2g_small_linear_grads(int n_jobs, const float* const* dy, const float* const* x, float* const* dW,
+                           float* const* db, const int* n_out, const int* n_in, int batch, void* stream) {
+  if (n_jobs < 1 || n_jobs > 4 || !dy || !x || !dW || !db || !n_out || !n_in || batch < 1 || batch > 4096) return -1;
+  S2GSmallDw a;
+  a.n_jobs = n_jobs;
+  a.batch = batch;
+  for (int j = 0; j < n_jobs; ++j) {
+    if (!dy[j] || !x[j] || !dW[j] || n_out[j] < 1 || n_in[j] < 4 || (n_in[j] & 3)) return -1;
+    if ((long)n_out[j] * n_in[j] > (1L << 26)) return -1;                   // small layers only
+    if ((((uintptr_t)x[j]) | ((uintptr_t)dW[j])) & 15) return -1;
+    a.dy[j] = dy[j]; a.x[j] = x[j]; a.dW[j] = dW[j]; a.db[j] = db[j];
+    a.n_out[j] = n_out[j]; a.n_in[j] = n_in[j];
+  }
+  return s2g_launch_small_dw(&a, ST(stream));
 }
 
 int s2g_generate_tokens(const float* W, const float* x, const float* bias, const float* U, long long* tokens, int L,

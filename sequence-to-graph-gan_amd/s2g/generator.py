@@ -202,6 +202,10 @@ class GeneratorEngine:
         ops.linear_bwd_dw(dl2, a3, g["model.8.weight"], scratch)
         ops.colsum(dl2, dl2.shape[0], self.L * self.V, self.L * self.V, g["model.8.bias"], scratch)
 
+    def last_layer_bias_grad(self, dl2: torch.Tensor, scratch: ops.Scratch) -> None:
+        """Bias gradient of the output Linear alone (its weight gradient is consumed inside the fused update)."""
+        ops.colsum(dl2, dl2.shape[0], self.L * self.V, self.L * self.V, self.grads.views["model.8.bias"], scratch)
+
     def last_layer_range(self):
         """[lo, hi) of the output Linear's weight and bias in the flat parameter buffer (adjacent views)."""
         lo = self.params.offsets["model.8.weight"][0]
@@ -229,20 +233,19 @@ class GeneratorEngine:
             self.last_layer_grads(dl2, s["a3"], sc)
         else:
             last_layer(dl2, s["a3"])
+        # the chain d(a3) -> d(x0) first (every link waits for the one before), then the weight and bias
+        # gradients of the three small layers, which hang off it, in ONE launch
         dpre3 = self._bn_bwd(s["a3"], da3, s["xhat3"], s["inv3"], "model.6", B, 512)
-        ops.linear_bwd_dw(dpre3, s["a2"], g["model.5.weight"], sc)
-        ops.colsum(dpre3, B, 512, 512, g["model.5.bias"], sc)
         da2 = torch.empty(B, 256, device=dev)
         ops.linear_bwd_dx(dpre3, p["model.5.weight"], da2, sc)
         dpre2 = self._bn_bwd(s["a2"], da2, s["xhat2"], s["inv2"], "model.3", B, 256)
-        ops.linear_bwd_dw(dpre2, s["a1"], g["model.2.weight"], sc)
-        ops.colsum(dpre2, B, 256, 256, g["model.2.bias"], sc)
         da1 = torch.empty(B, 128, device=dev)
         ops.linear_bwd_dx(dpre2, p["model.2.weight"], da1, sc)
         call("s2g_lrelu_bwd", ptr(s["a1"]), ptr(da1), da1.numel(), stream_ptr())
-        ops.linear_bwd_dw(da1, s["x0"], g["model.0.weight"], sc)
-        ops.colsum(da1, B, 128, 128, g["model.0.bias"], sc)
         dx0 = torch.empty(B, LATENT, device=dev)
         ops.linear_bwd_dx(da1, p["model.0.weight"], dx0, sc)
+        ops.small_linear_grads([(dpre3, s["a2"], g["model.5.weight"], g["model.5.bias"]),
+                                (dpre2, s["a1"], g["model.2.weight"], g["model.2.bias"]),
+                                (da1, s["x0"], g["model.0.weight"], g["model.0.bias"])])
         call("s2g_embed_mul_bwd", ptr(s["z"]), ptr(s["labels"]), ptr(dx0), ptr(g["label_embedding.weight"]), B,
              LATENT, self.n_classes, stream_ptr())

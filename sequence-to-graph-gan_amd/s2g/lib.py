@@ -64,6 +64,8 @@ SIGNATURES = {
     "s2g_gemm_grouped": [P, P, I, I, I, P],
     "s2g_generate_tokens": [P, P, P, P, P, I, I, I, I, U64, U64, P],
     "s2g_linear_small_batch": [P, P, P, P, I, I, I, I, P],
+    "s2g_linear_wgrad_adam": [P, P, P, P, P, P, I, I, I, F, F, F, F, I, I, P],
+    "s2g_small_linear_grads": [I, P, P, P, P, P, P, I, P],
     "s2g_critic_update": [ctypes.POINTER(S2GCriticUpdate), P],
     "s2g_reduce_slabs": [P, L, I, I, I, P, I, I, F, P],
     "s2g_reduce_slabs_multi": [P, I, I, I, F, P],

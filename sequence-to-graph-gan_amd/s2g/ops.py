@@ -114,6 +114,31 @@ def linear_fwd_small_batch(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.T
     call("s2g_linear_small_batch", ptr(W), ptr(x), ptr(b), ptr(y), N, M, K, int(workgroups), stream_ptr())
 
 
+def linear_wgrad_adam_ok(batch: int, K: int) -> bool:
+    """Shapes the fused weight-gradient + Adam kernel takes (s2g_linear_wgrad_adam)."""
+    return batch <= 64 and K in (256, 512)
+
+
+def linear_wgrad_adam(dy: torch.Tensor, a: torch.Tensor, W: torch.Tensor, m: torch.Tensor, v: torch.Tensor, lr: float,
+                      b1: float, b2: float, eps: float, step: int, grad: Optional[torch.Tensor] = None,
+                      workgroups: int = 0) -> None:
+    """Adam step of W[N,K] on the gradient dy[M,N]^T @ a[M,K] without materialising it (grad: optional
+    tensor that also receives the gradient).  workgroups: CUs the current stream can reach (0: all)."""
+    M, N = dy.shape
+    K = a.shape[1]
+    for t, n in ((dy, "dy"), (a, "a"), (W, "W"), (m, "m"), (v, "v")):
+        _chk(t, name=n)
+    if grad is not None:
+        _chk(grad, name="grad")
+    if a.shape[0] != M or W.numel() != N * K or m.numel() != N * K or v.numel() != N * K or \
+            (grad is not None and grad.numel() != N * K):
+        raise S2GError("linear_wgrad_adam: shape mismatch")
+    if not linear_wgrad_adam_ok(M, K):
+        raise S2GError("linear_wgrad_adam: batch <= 64 and K = 256 or 512 required")
+    call("s2g_linear_wgrad_adam", ptr(dy), ptr(a), ptr(W), ptr(m), ptr(v), ptr(grad), N, M, K, lr, b1, b2, eps,
+         int(step), int(workgroups), stream_ptr())
+
+
 def linear_bwd_dx(dy: torch.Tensor, W: torch.Tensor, dx: torch.Tensor, scratch: Scratch) -> None:
     """dx[M,K] = dy[M,N] @ W[N,K]"""
     M, N = dy.shape
@@ -141,6 +166,28 @@ def linear_bwd_dw(dy: torch.Tensor, x: torch.Tensor, dW: torch.Tensor, scratch: 
         slabs = scratch.get(ns * N * K)
         gemm_raw(ptr(dy), 1, N, ptr(x), K, 1, ptr(slabs), K, N, K, M, nsplit=ns, slab=N * K)
         reduce_slabs(slabs, N * K, ns, N, K, dW, accumulate=accumulate)
+
+
+def small_linear_grads(jobs) -> None:
+    """jobs: up to four (dy[M,N], x[M,K], dW[N,K], db[N] or None) of small Linear layers sharing the batch M:
+    dW = dy^T x and db = column sums of dy, all in one launch (s2g_small_linear_grads)."""
+    import ctypes
+    n = len(jobs)
+    if not 1 <= n <= 4:
+        raise S2GError("small_linear_grads: 1..4 jobs")
+    M = jobs[0][0].shape[0]
+    for dy, x, dW, db in jobs:
+        for t, nm in ((dy, "dy"), (x, "x"), (dW, "dW")):
+            _chk(t, name=nm)
+        if db is not None:
+            _chk(db, name="db")
+        if dy.shape[0] != M or x.shape[0] != M or tuple(dW.shape) != (dy.shape[1], x.shape[1]) or \
+                (db is not None and db.numel() != dy.shape[1]):
+            raise S2GError("small_linear_grads: shape mismatch")
+    PA, IA = ctypes.c_void_p * n, ctypes.c_int * n
+    call("s2g_small_linear_grads", n, PA(*[ptr(j[0]) for j in jobs]), PA(*[ptr(j[1]) for j in jobs]),
+         PA(*[ptr(j[2]) for j in jobs]), PA(*[ptr(j[3]) for j in jobs]), IA(*[j[0].shape[1] for j in jobs]),
+         IA(*[j[1].shape[1] for j in jobs]), M, stream_ptr())
 
 
 def colsum(X: torch.Tensor, rows: int, cols: int, ld: int, out: torch.Tensor, scratch: Scratch,

@@ -244,10 +244,13 @@ class WGANGPTrainer:
 
     def _generator_step(self, labels: Optional[torch.Tensor] = None, z: Optional[torch.Tensor] = None,
                        U: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
-                       wsum: Optional[float] = None, update: bool = True, defer_join: bool = False):
+                       wsum: Optional[float] = None, update: bool = True, defer_join: bool = False,
+                       keep_grads: bool = True):
         """wgan_gp.py:330-343 with the z / labels of the preceding critic_step by default.
         defer_join: return while the output Linear's update may still run on the side stream; the next
-        generator forward waits for it just before that layer (full_step uses this)."""
+        generator forward waits for it just before that layer (full_step uses this).
+        keep_grads: False lets the output Linear's weight gradient stay in registers (one process: its
+        product and its Adam step are one kernel); G.grads then holds every gradient but that one."""
         labels = self.last["labels"] if labels is None else labels
         z = self.last["z"] if z is None else z
         wsum = self.last["wsum"] if wsum is None else wsum
@@ -269,11 +272,34 @@ class WGANGPTrainer:
             mask = dropout_mask(B * self.L, self.drop_rate, self.device, self.rng)
         losses, dfake = critic_forward_backward_fake(self.D, fake, labels, n_global, 1.0 / wsum, mask, CLASS_W)
         side = self.D.side() if (update and self.D.overlap) else None
+        lo, hi = self.G.last_layer_range()
+        # one process and a batch the kernel takes: the output Linear's weight gradient and its Adam step in ONE
+        # pass over W, m, v (6 passes over 184 MB instead of 10); with several ranks the gradient must be
+        # all-reduced first, so the product and the flat Adam stay separate
+        fused_out = update and not self.comm.split and ops.linear_wgrad_adam_ok(B, self.G.params.views["model.8.weight"].shape[1])
+
+        def last_layer_update(dl2, a3, workgroups=0):
+            """gradients and Adam step of the output Linear (weight and bias) on the current stream"""
+            if not fused_out:
+                self.G.last_layer_grads(dl2, a3, self._g_scratch)
+                self._adam(self.G, self.mG, self.vG, self.tG, lo, hi)
+                return
+            ow, nw, _ = self.G.params.offsets["model.8.weight"]
+            lr, b1, b2, eps = self.adam_g
+            ops.linear_wgrad_adam(dl2, a3, self.G.params.flat[ow:ow + nw], self.mG[ow:ow + nw], self.vG[ow:ow + nw],
+                                  lr, b1, b2, eps, self.tG,
+                                  grad=self.G.grads.flat[ow:ow + nw] if keep_grads else None, workgroups=workgroups)
+            self.G.last_layer_bias_grad(dl2, self._g_scratch)
+            self._adam(self.G, self.mG, self.vG, self.tG, ow + nw, hi)
+
         if side is None:
-            self.G.backward(dfake)
             if update:
                 self.tG += 1
-                self._adam(self.G, self.mG, self.vG, self.tG)
+                self.G.backward(dfake, last_layer=last_layer_update)
+                self._adam(self.G, self.mG, self.vG, self.tG, 0, lo)
+                self._adam(self.G, self.mG, self.vG, self.tG, hi, self.G.params.total)
+            else:
+                self.G.backward(dfake)
         else:
             # The output Linear holds 99.6 % of the parameters: its weight gradient and Adam update are
             # HBM-bound and independent of the rest of the backward (a chain of small kernels), so they
@@ -282,7 +308,6 @@ class WGANGPTrainer:
             self._join_generator()
             self.tG += 1
             stream_s = side[0]
-            lo, hi = self.G.last_layer_range()
             done, keep = torch.cuda.Event(), []
 
             def last_layer(dl2, a3):
@@ -291,8 +316,7 @@ class WGANGPTrainer:
                 keep.extend((dl2, a3))        # allocated on this stream, read on the other: alive until the join
                 with torch.cuda.stream(stream_s):
                     stream_s.wait_event(ready)
-                    self.G.last_layer_grads(dl2, a3, self._g_scratch)
-                    self._adam(self.G, self.mG, self.vG, self.tG, lo, hi)
+                    last_layer_update(dl2, a3, self.D.cu_masked)
                     done.record()
 
             self.G.backward(dfake, last_layer=last_layer)
@@ -361,5 +385,5 @@ class WGANGPTrainer:
                 self._critic_step(tokens, labels, lengths, wsum, nz.get("z"), nz.get("U"), nz.get("alpha"),
                                   nz.get("mask"), next_batch=nxt, gen_next=gen)
                 if i % self.n_critic == 0:
-                    self._generator_step(U=nz.get("U2"), mask=nz.get("mask_g"), defer_join=i + 1 < n)
+                    self._generator_step(U=nz.get("U2"), mask=nz.get("mask_g"), defer_join=i + 1 < n, keep_grads=False)
             self._join_generator()

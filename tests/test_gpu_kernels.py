@@ -456,3 +456,69 @@ def test_gemm_tall_bf16_strided_operands():
     want = A[:, :K].bfloat16().double() @ B[:, :N].bfloat16().double()
     assert rel(C[:, :N], want) < 1e-5
     assert torch.isnan(C[:, N:]).all()          # nothing written outside the N columns
+
+
+@pytest.mark.parametrize("B,N,K", [(64, 89600, 512), (5, 1000, 256), (16, 4112, 512)])
+def test_linear_wgrad_adam_matches_unfused(B, N, K):
+    """The fused weight-gradient + Adam step of the generator's output layer against torch.optim.Adam on the
+    float64 gradient dy^T a, two updates in a row (the second with moments that are no longer zero); the
+    optional gradient output against the same product.  N = 1000 and 4112 leave a partial / odd last block."""
+    from s2g import lib, ops
+    g = common.gen(77)
+    W0 = (torch.randn(N, K, generator=g) * 0.05)
+    Wr = W0.double().clone().requires_grad_(True)
+    opt = torch.optim.Adam([Wr], lr=2e-4, betas=(0.5, 0.999), eps=1e-8)
+    W = W0.to(DEV)
+    m, v = torch.zeros_like(W), torch.zeros_like(W)
+    grad = torch.full_like(W, float("nan"))
+    for step in (1, 2):
+        dy = (torch.randn(B, N, generator=g) * 1e-3)
+        a = torch.randn(B, K, generator=g)
+        gref = dy.double().t() @ a.double()
+        Wr.grad = gref.clone()
+        W_before = Wr.detach().clone()
+        opt.step()
+        Wd_before = W.clone()
+        ops.linear_wgrad_adam(dy.to(DEV), a.to(DEV), W, m, v, 2e-4, 0.5, 0.999, 1e-8, step,
+                              grad=grad if step == 1 else None, workgroups=0 if step == 1 else 192)
+        torch.cuda.synchronize()
+        if step == 1:
+            assert rel(grad.cpu(), gref) < 1e-5
+        st = opt.state[Wr]
+        assert rel(m.cpu(), st["exp_avg"]) < 1e-5
+        assert rel(v.cpu(), st["exp_avg_sq"]) < 1e-4      # 1 - 0.999 in fp32 is 1.00005e-3
+        # the UPDATE, not the parameter (an Adam step moves an element by ~lr); where |g| is within a few orders
+        # of eps * sqrt(v)'s rounding the step is ill-conditioned, so compare where the gradient is not tiny
+        firm = gref.abs() >= 1e-6
+        du, du_ref = (W.cpu().double() - Wd_before.cpu().double())[firm], (Wr.detach() - W_before)[firm]
+        assert float((du - du_ref).norm() / du_ref.norm()) < 1e-3
+    L = lib.get()
+    s = torch.cuda.current_stream().cuda_stream
+    p = W.data_ptr()
+    assert L.s2g_linear_wgrad_adam(p, p, p, p, p, None, N, 65, K, 2e-4, 0.5, 0.999, 1e-8, 1, 0, s) == -1     # batch > 64
+    assert L.s2g_linear_wgrad_adam(p, p, p, p, p, None, N, 8, 128, 2e-4, 0.5, 0.999, 1e-8, 1, 0, s) == -1    # K = 256 or 512
+    assert L.s2g_linear_wgrad_adam(p, p, p + 4, p, p, None, N, 8, K, 2e-4, 0.5, 0.999, 1e-8, 1, 0, s) == -1  # alignment
+    assert L.s2g_linear_wgrad_adam(p, p, p, p, p, None, N, 8, K, 2e-4, 0.5, 0.999, 1e-8, 0, 0, s) == -1      # step >= 1
+
+
+@pytest.mark.parametrize("M", [64, 5])
+def test_small_linear_grads_match_torch(M):
+    """One launch for the weight and bias gradients of the generator's three small Linear layers against the
+    float64 products dy^T x and column sums (shapes of wgan_gp.py:147-156)."""
+    from s2g import lib, ops
+    g = common.gen(91)
+    jobs, refs = [], []
+    for n_out, n_in, with_bias in ((512, 256, True), (256, 128, True), (128, 100, False)):
+        dy, x = torch.randn(M, n_out, generator=g), torch.randn(M, n_in, generator=g)
+        dW = torch.full((n_out, n_in), float("nan"), device=DEV)
+        db = torch.full((n_out,), float("nan"), device=DEV) if with_bias else None
+        jobs.append((dy.to(DEV), x.to(DEV), dW, db))
+        refs.append((dy.double().t() @ x.double(), dy.double().sum(0)))
+    ops.small_linear_grads(jobs)
+    torch.cuda.synchronize()
+    for (dy, x, dW, db), (rW, rb) in zip(jobs, refs):
+        assert rel(dW.cpu(), rW) < 1e-5
+        if db is not None:
+            assert rel(db.cpu(), rb) < 1e-5
+    with pytest.raises(lib.S2GError):
+        ops.small_linear_grads([(jobs[0][0], jobs[1][1], jobs[0][2], None)])      # dW shape does not match x

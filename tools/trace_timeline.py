@@ -22,8 +22,10 @@ def main():
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r["Queue_Id"]), short(r["Kernel_Name"]),
                          int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1)))
     rows.sort()
-    # a full step ends with the generator's Adam (the largest s2g_k_adam grid); take the last two
-    adam = [i for i, r in enumerate(rows) if r[3].startswith("s2g_k_adam") and r[4] > 1000]
+    # a full step ends with the generator's output-layer update (the largest s2g_k_adam grid, or the fused
+    # weight-gradient + Adam kernel); take the last two
+    adam = [i for i, r in enumerate(rows) if (r[3].startswith("s2g_k_adam") and r[4] > 1000)
+            or r[3].startswith("s2g_k_linear_wgrad_adam")]
     lo, hi = adam[-2] + 1, adam[-1] + 1
     step = rows[lo:hi]
     t0 = step[0][0]

@@ -350,7 +350,7 @@ def train_wgan(generator, discriminator, optimizer_G, optimizer_D, train_dataloa
                                next_batch=ahead, gen_next=dict(U=U2) if gen_now else None)
                 if gen_now:
                     # (the output layer's update may still run on the side stream: the next forward waits for it)
-                    tr.generator_step(U=U2, defer_join=True)
+                    tr.generator_step(U=U2, defer_join=True, keep_grads=False)
                     d_loss, g_loss = tr.losses().tolist()
                     print(
                         "[Epoch %d/%d] [Batch %d/%d] [D loss: %f] [G loss: %f]"
