@@ -350,11 +350,15 @@ int s2g_lstm64_bwd(const float* dh_in, const float* whh, const int* lengths, int
  * (wgan.py:39-42, 107-111); soft != 0: columns 0..31 already hold y @ emb (the matmul branch, :45). */
 int s2g_embed_concat(const int* tokens, const float* emb, int V, const long long* labels, const float* lab_emb,
                      int n_classes, int T, long rows, int soft, float* x, void* stream);
-/* gradients of the two lookups from dx [rows, 64] (live rows only) */
+/* gradients of the two lookups from dx [rows, 64] (live rows only; what backward() leaves in
+ * sequence_embedding.embed_layer.weight.grad / label_embedding.weight.grad, wgan.py:39-42, 107-111), each as a
+ * two-stage sum with a fixed order of additions.  part: scratch of s2g_embed_grad_tokens_scratch(rows, V) floats
+ * (tokens; V <= 320) / B * 32 floats (labels). */
+long s2g_embed_grad_tokens_scratch(long rows, int V);
 int s2g_embed_grad_tokens(const int* tokens, const int* lengths, int T, long rows, int V, const float* dx, float* demb,
-                          int accumulate, void* stream);
+                          int accumulate, float* part, void* stream);
 int s2g_embed_grad_labels(const long long* labels, const int* lengths, int T, int B, int n_classes, const float* dx,
-                          float* dlab, int accumulate, void* stream);
+                          float* dlab, int accumulate, float* part, void* stream);
 /* Attention pooling + output Linear of the critic (wgan.py:82-89, 116-118) over the first Tp = max(lengths) steps:
  * pre [rows, 64] = out Wa^T + ba on entry, tanh(pre) on return; weights [nseq, T], pooled [nseq, 64], dval [nseq]. */
 int s2g_attnpool_fwd(float* pre, const float* out, const float* wc, const float* wl, const float* bl, int nseq, int T,

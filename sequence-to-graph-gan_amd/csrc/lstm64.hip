@@ -135,48 +135,89 @@ extern "C" __global__ void s2g_k_embed_concat(const int* __restrict__ tokens, co
   }
 }
 
-// gradient of the lookup branch: demb[token[row]] += dx[row][0:32] for live rows (t < len); one workgroup per
-// vocabulary entry scans the tokens (V workgroups, deterministic order of additions inside a thread column).
-extern "C" __global__ __launch_bounds__(256) void s2g_k_embed_grad_tokens(const int* __restrict__ tokens,
-                                                                          const int* __restrict__ lengths, int T,
-                                                                          long rows, int V, const float* __restrict__ dx,
-                                                                          float* __restrict__ demb, int accumulate) {
-  __shared__ float red[8][32];
-  const int v = blockIdx.x, c = threadIdx.x & 31, g = threadIdx.x >> 5;
-  float s = 0.0f;
-  for (long r = g; r < rows; r += 8) {
-    const int tok = min(max(tokens[r], 0), V - 1);
-    if (tok == v && (int)(r % T) < lengths[r / T]) s += dx[r * 64 + c];
+// gradient of the lookup branch: demb[token[row]] += dx[row][0:32] for live rows (t < len), in two launches with a
+// fixed order of additions (no float atomics).  Stage 1: a workgroup owns EG_CHUNK consecutive rows; each of its four
+// 32-thread groups walks a quarter of them in ascending order, adding row r's 32 columns into its own [V][32] table in
+// LDS at the row's token (the 32 threads of a group own distinct columns); the four tables are added in order and the
+// chunk's table goes to part[chunk][V * 32].  Stage 2 (s2g_k_embed_grad_final) adds the chunks in ascending order.
+#define EG_CHUNK 1024
+#define EG_GROUPS 4
+extern "C" __global__ __launch_bounds__(32 * EG_GROUPS) void s2g_k_embed_grad_tokens_part(
+    const int* __restrict__ tokens, const int* __restrict__ lengths, int T, long rows, int V,
+    const float* __restrict__ dx, float* __restrict__ part) {
+  extern __shared__ float eg_tab[];      // [EG_GROUPS][V * 32]
+  const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int n = V * 32;
+  for (int i = threadIdx.x; i < EG_GROUPS * n; i += 32 * EG_GROUPS) eg_tab[i] = 0.0f;
+  __syncthreads();
+  float* tab = eg_tab + g * n;
+  const long r0 = (long)blockIdx.x * EG_CHUNK + (long)g * (EG_CHUNK / EG_GROUPS);
+  const long r1 = min(r0 + EG_CHUNK / EG_GROUPS, rows);
+  for (long rb = r0; rb < r1; rb += 8) {
+    // eight rows' loads first (independent), then their additions in ascending row order
+    float v[8];
+    int tk[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const long r = min(rb + k, rows - 1);
+      const bool live = rb + k < r1 && (int)(r % T) < lengths[r / T];
+      tk[k] = live ? min(max(tokens[r], 0), V - 1) : -1;
+      v[k] = dx[r * 64 + c];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (tk[k] >= 0) tab[tk[k] * 32 + c] += v[k];
   }
-  red[g][c] = s;
+  __syncthreads();
+  float* out = part + (size_t)blockIdx.x * n;
+  for (int i = threadIdx.x; i < n; i += 32 * EG_GROUPS)
+    out[i] = ((eg_tab[i] + eg_tab[n + i]) + eg_tab[2 * n + i]) + eg_tab[3 * n + i];
+}
+
+// out[i] (+)= part[0][i] + part[1][i] + ... (ascending), i < n
+extern "C" __global__ __launch_bounds__(256) void s2g_k_embed_grad_final(const float* __restrict__ part, int nchunks,
+                                                                         int n, float* __restrict__ out,
+                                                                         int accumulate) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.0f;
+  for (int k = 0; k < nchunks; ++k) s += part[(size_t)k * n + i];
+  out[i] = accumulate ? out[i] + s : s;
+}
+
+// gradient of the label half: dlab[l] (+)= sum over sequences with label l and live rows of dx[row][32:64].
+// Stage 1: one workgroup per sequence sums its live rows (8 groups of 32 columns, fixed order) into part[b][32];
+// stage 2: one workgroup per class adds the sequences of that class in ascending order.
+extern "C" __global__ __launch_bounds__(256) void s2g_k_embed_grad_labels_part(const int* __restrict__ lengths, int T,
+                                                                               const float* __restrict__ dx,
+                                                                               float* __restrict__ part) {
+  __shared__ float red[8][32];
+  const int b = blockIdx.x, c = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int len = lengths ? min(max(lengths[b], 0), T) : T;
+  const float* p = dx + (size_t)b * T * 64 + 32 + c;
+  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+  int t = g;
+  for (; t + 24 < len; t += 32) {
+    s0 += p[(size_t)t * 64]; s1 += p[(size_t)(t + 8) * 64]; s2 += p[(size_t)(t + 16) * 64]; s3 += p[(size_t)(t + 24) * 64];
+  }
+  for (; t < len; t += 8) s0 += p[(size_t)t * 64];
+  red[g][c] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (g == 0) {
-    float t = 0.0f;
-    for (int k = 0; k < 8; ++k) t += red[k][c];
-    demb[v * 32 + c] = accumulate ? demb[v * 32 + c] + t : t;
+    float r = 0.0f;
+    for (int k = 0; k < 8; ++k) r += red[k][c];
+    part[b * 32 + c] = r;
   }
 }
 
-// gradient of the label half: dlab[l] (+)= sum over sequences with label l and live rows of dx[row][32:64]
-extern "C" __global__ __launch_bounds__(256) void s2g_k_embed_grad_labels(const long long* __restrict__ labels,
-                                                                          const int* __restrict__ lengths, int T, int B,
-                                                                          const float* __restrict__ dx,
-                                                                          float* __restrict__ dlab, int accumulate) {
-  __shared__ float red[8][32];
-  const int l = blockIdx.x, c = threadIdx.x & 31, g = threadIdx.x >> 5;
+extern "C" __global__ __launch_bounds__(32) void s2g_k_embed_grad_labels(const long long* __restrict__ labels, int B,
+                                                                         const float* __restrict__ part,
+                                                                         float* __restrict__ dlab, int accumulate) {
+  const int l = blockIdx.x, c = threadIdx.x;
   float s = 0.0f;
-  for (int b = 0; b < B; ++b) {
-    if (labels[b] != l) continue;
-    const int len = lengths ? min(lengths[b], T) : T;
-    for (int t = g; t < len; t += 8) s += dx[((long)b * T + t) * 64 + 32 + c];
-  }
-  red[g][c] = s;
-  __syncthreads();
-  if (g == 0) {
-    float t = 0.0f;
-    for (int k = 0; k < 8; ++k) t += red[k][c];
-    dlab[l * 32 + c] = accumulate ? dlab[l * 32 + c] + t : t;
-  }
+  for (int b = 0; b < B; ++b)
+    if (labels[b] == l) s += part[b * 32 + c];
+  dlab[l * 32 + c] = accumulate ? dlab[l * 32 + c] + s : s;
 }
 
 // ---- attention pooling (wgan.py:82-89, 116-118) over Tp = the longest sequence of the batch (what

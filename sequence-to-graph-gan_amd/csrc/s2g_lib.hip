@@ -570,17 +570,33 @@ int s2g_embed_concat(const int* tokens, const float* emb, int V, const long long
                      lab_emb, n_classes, T, rows, soft, x);
   return LAUNCH_OK();
 }
+long s2g_embed_grad_tokens_scratch(long rows, int V) {
+  if (rows <= 0 || V <= 0) return -1;
+  return ((rows + EG_CHUNK - 1) / EG_CHUNK) * (long)V * 32;
+}
 int s2g_embed_grad_tokens(const int* tokens, const int* lengths, int T, long rows, int V, const float* dx, float* demb,
-                          int accumulate, void* stream) {
-  if (!tokens || !lengths || !dx || !demb || T <= 0 || rows <= 0 || V <= 0) return -1;
-  hipLaunchKernelGGL(s2g_k_embed_grad_tokens, dim3(V), dim3(256), 0, ST(stream), tokens, lengths, T, rows, V, dx, demb,
-                     accumulate);
+                          int accumulate, float* part, void* stream) {
+  if (!tokens || !lengths || !dx || !demb || !part || T <= 0 || rows <= 0 || V <= 0) return -1;
+  const size_t lds = (size_t)EG_GROUPS * V * 32 * sizeof(float);   // four tables of V x 32 floats in LDS
+  if (lds > 160 * 1024) return -1;                                 // V <= 320
+  static bool attr_done = false;
+  if (!attr_done) {
+    S2G_CHECK(hipFuncSetAttribute((const void*)s2g_k_embed_grad_tokens_part, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024));
+    attr_done = true;
+  }
+  const int nchunks = (int)((rows + EG_CHUNK - 1) / EG_CHUNK);
+  hipLaunchKernelGGL(s2g_k_embed_grad_tokens_part, dim3(nchunks), dim3(32 * EG_GROUPS), lds, ST(stream), tokens, lengths,
+                     T, rows, V, dx, part);
+  hipLaunchKernelGGL(s2g_k_embed_grad_final, dim3(cdiv((long)V * 32, 256)), dim3(256), 0, ST(stream), part, nchunks,
+                     V * 32, demb, accumulate);
   return LAUNCH_OK();
 }
 int s2g_embed_grad_labels(const long long* labels, const int* lengths, int T, int B, int n_classes, const float* dx,
-                          float* dlab, int accumulate, void* stream) {
-  if (!labels || !dx || !dlab || T <= 0 || B <= 0 || n_classes <= 0) return -1;
-  hipLaunchKernelGGL(s2g_k_embed_grad_labels, dim3(n_classes), dim3(256), 0, ST(stream), labels, lengths, T, B, dx, dlab,
+                          float* dlab, int accumulate, float* part, void* stream) {
+  if (!labels || !dx || !dlab || !part || T <= 0 || B <= 0 || n_classes <= 0) return -1;
+  hipLaunchKernelGGL(s2g_k_embed_grad_labels_part, dim3(B), dim3(256), 0, ST(stream), lengths, T, dx, part);
+  hipLaunchKernelGGL(s2g_k_embed_grad_labels, dim3(n_classes), dim3(32), 0, ST(stream), labels, B, part, dlab,
                      accumulate);
   return LAUNCH_OK();
 }

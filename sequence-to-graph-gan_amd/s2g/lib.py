@@ -107,8 +107,9 @@ SIGNATURES = {
     "s2g_lstm64_fwd": [P, P, P, I, I, P, P, P, P, P, P],
     "s2g_lstm64_bwd": [P, P, P, I, I, P, P, P, P],
     "s2g_embed_concat": [P, P, I, P, P, I, I, L, I, P, P],
-    "s2g_embed_grad_tokens": [P, P, I, L, I, P, P, I, P],
-    "s2g_embed_grad_labels": [P, P, I, I, I, P, P, I, P],
+    "s2g_embed_grad_tokens_scratch": [L, I],
+    "s2g_embed_grad_tokens": [P, P, I, L, I, P, P, I, P, P],
+    "s2g_embed_grad_labels": [P, P, I, I, I, P, P, I, P, P],
     "s2g_attnpool_fwd": [P, P, P, P, P, I, I, I, P, P, P, P],
     "s2g_attnpool_bwd": [P, P, P, P, P, P, I, I, I, P, P, P],
     "s2g_wasserstein_loss": [P, I, P, P, P],
@@ -140,6 +141,7 @@ def load(path: str = LIB_PATH) -> ctypes.CDLL:
         fn.argtypes = argtypes
         fn.restype = ctypes.c_int
     lib.s2g_graph_features_workspace.restype = ctypes.c_long      # a byte count
+    lib.s2g_embed_grad_tokens_scratch.restype = ctypes.c_long     # a float count
     return lib
 
 

@@ -207,10 +207,12 @@ class ClipCriticEngine:
             lens = st["lengths"]
             if lens is None:
                 lens = torch.full((B,), T, dtype=torch.int32, device=dev)
+            part = sc.get(((rows + 1023) // 1024) * self.V * 32)       # = s2g_embed_grad_tokens_scratch(rows, V)
             call("s2g_embed_grad_tokens", ptr(st["seq"]), ptr(lens), T, rows, self.V, ptr(dx), ptr(ge), int(accumulate),
-                 stream_ptr())
+                 ptr(part), stream_ptr())
+        part = sc.get(B * 32)
         call("s2g_embed_grad_labels", ptr(st["labels"]), ptr(st["lengths"]), T, B, self.n_classes, ptr(dx),
-             ptr(g["label_embedding.weight"]), int(accumulate), stream_ptr())
+             ptr(g["label_embedding.weight"]), int(accumulate), ptr(part), stream_ptr())
 
     def dropout_masks(self, rows: int):
         if self.dropout <= 0.0:

@@ -117,3 +117,36 @@ def test_module_surface_and_train_step_follow_the_reference(golden):
         torch.randint, torch.rand = real_randint, real_rand
     for n, v in D.state_dict().items():            # the module's parameters ARE the engine's (two updates by now)
         assert float(v.abs().max()) <= 0.1 + 1e-7
+
+
+@pytest.mark.parametrize("B,T,V", [(5, 37, 175), (128, 1024, 175)])
+def test_embedding_gradients_match_index_add(B, T, V):
+    """The two-stage embedding gradients (tokens and labels) against index_add in float64: live rows only,
+    written and accumulated, at a small ragged shape and at the benchmark's shape (rows span many chunks)."""
+    from s2g.lib import call, get
+    from s2g.ops import ptr, stream_ptr
+    g = common.gen(5)
+    tokens = torch.randint(0, V, (B, T), generator=g, dtype=torch.int32)
+    lengths = torch.randint(1, T + 1, (B,), generator=g, dtype=torch.int32)
+    lengths[0] = T
+    labels = torch.randint(0, 2, (B,), generator=g)
+    dx = torch.randn(B * T, 64, generator=g)
+    live = (torch.arange(T)[None, :] < lengths[:, None]).reshape(-1)
+    ref_e = torch.zeros(V, 32, dtype=torch.float64).index_add_(0, tokens.reshape(-1)[live].long(), dx[live, :32].double())
+    per_seq = (dx[:, 32:].double() * live[:, None]).view(B, T, 32).sum(1)
+    ref_l = torch.zeros(2, 32, dtype=torch.float64).index_add_(0, labels, per_seq)
+    L = get()
+    n_part = L.s2g_embed_grad_tokens_scratch(B * T, V)
+    assert n_part == ((B * T + 1023) // 1024) * V * 32
+    part = torch.empty(max(n_part, B * 32), device=DEV)
+    de = torch.full((V, 32), 0.5, device=DEV)
+    dl = torch.full((2, 32), 0.25, device=DEV)
+    args_t = (ptr(tokens.to(DEV)), ptr(lengths.to(DEV)), T, B * T, V, ptr(dx.to(DEV)))
+    tk, ln, lb, dxd = tokens.to(DEV), lengths.to(DEV), labels.to(DEV), dx.to(DEV)
+    for accumulate, base_e, base_l in ((0, 0.0, 0.0), (1, 1.0, 1.0)):
+        call("s2g_embed_grad_tokens", ptr(tk), ptr(ln), T, B * T, V, ptr(dxd), ptr(de), accumulate, ptr(part), stream_ptr())
+        call("s2g_embed_grad_labels", ptr(lb), ptr(ln), T, B, 2, ptr(dxd), ptr(dl), accumulate, ptr(part), stream_ptr())
+        torch.cuda.synchronize()
+        k = 1 + accumulate
+        assert (de.cpu().double() - k * ref_e).abs().max() <= 1e-5 * ref_e.abs().max()
+        assert (dl.cpu().double() - k * ref_l).abs().max() <= 1e-5 * ref_l.abs().max()
