@@ -37,22 +37,23 @@ extern "C" __global__ __launch_bounds__(X_G) void s2g_k_lstm64_fwd(const float* 
   float nxt = len > 0 ? pin[r0 * X_G + j] : 0.0f;
   __syncthreads();
   for (int t = 0; t < len; ++t) {
-    float a = nxt;
-    if (t + 1 < len) nxt = pin[(r0 + t + 1) * X_G + j];          // next step's input part, ahead of its use
+    float a0 = nxt, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;             // four independent chains: issue-bound, not latency-bound
+    nxt = pin[(r0 + min(t + 1, len - 1)) * X_G + j];             // next step's input part, ahead of its use
     const float4* h4 = reinterpret_cast<const float4*>(hs);
 #pragma unroll
     for (int k = 0; k < X_H / 4; ++k) {
       const float4 hv = h4[k];
-      a = fmaf(w[4 * k], hv.x, a); a = fmaf(w[4 * k + 1], hv.y, a);
-      a = fmaf(w[4 * k + 2], hv.z, a); a = fmaf(w[4 * k + 3], hv.w, a);
+      a0 = fmaf(w[4 * k], hv.x, a0); a1 = fmaf(w[4 * k + 1], hv.y, a1);
+      a2 = fmaf(w[4 * k + 2], hv.z, a2); a3 = fmaf(w[4 * k + 3], hv.w, a3);
     }
-    const float g = (q == 2) ? tanhf(a) : 1.0f / (1.0f + expf(-a));
+    const float a = (a0 + a1) + (a2 + a3);
+    const float g = (q == 2) ? fast_tanh(a) : fast_sigmoid(a);
     gs[j] = g;
     gates[(r0 + t) * X_G + j] = g;
     __syncthreads();
     if (j < X_H) {
       c = fmaf(gs[X_H + j], c, gs[j] * gs[2 * X_H + j]);
-      const float h = gs[3 * X_H + j] * tanhf(c);
+      const float h = gs[3 * X_H + j] * fast_tanh(c);
       hs[j] = h;
       cst[(r0 + t) * X_H + j] = c;
       hout[(r0 + t) * X_H + j] = h;
@@ -88,20 +89,42 @@ extern "C" __global__ __launch_bounds__(X_G) void s2g_k_lstm64_bwd(const float* 
   ds[tid] = 0.0f;
   const size_t r0 = (size_t)n * T;
   float dc = 0.0f;
+  // saved values of the step in hand, fetched one step ahead by UNCONDITIONAL loads from clamped rows (a load
+  // inside the cell section would put a memory round trip on every step's critical path); lanes >= 64 of the
+  // first wave's siblings load too (harmless, same addresses modulo 64) so that no load sits under a branch
+  const int u0 = tid & 63;
+  float n_dh = 0.f, n_gi = 0.f, n_gf = 0.f, n_gg = 0.f, n_go = 0.f, n_c = 0.f, n_cp = 0.f;
+  if (len > 0) {
+    const size_t r = r0 + len - 1;
+    n_dh = dh_in[r * X_H + u0];
+    n_gi = gates[r * X_G + u0]; n_gf = gates[r * X_G + X_H + u0];
+    n_gg = gates[r * X_G + 2 * X_H + u0]; n_go = gates[r * X_G + 3 * X_H + u0];
+    n_c = cst[r * X_H + u0];
+    n_cp = cst[(r0 + max(len - 2, 0)) * X_H + u0];
+  }
   __syncthreads();
   for (int t = len - 1; t >= 0; --t) {
-    float s = 0.0f;
+    const float dhi = n_dh, gi = n_gi, gf = n_gf, gg = n_gg, go = n_go, ct = n_c;
+    const float cprev = t > 0 ? n_cp : 0.0f;
+    {
+      const size_t r = r0 + max(t - 1, 0);
+      n_dh = dh_in[r * X_H + u0];
+      n_gi = gates[r * X_G + u0]; n_gf = gates[r * X_G + X_H + u0];
+      n_gg = gates[r * X_G + 2 * X_H + u0]; n_go = gates[r * X_G + 3 * X_H + u0];
+      n_c = n_cp;
+      n_cp = cst[(r0 + max(t - 2, 0)) * X_H + u0];
+    }
+    const float tc = fast_tanh(ct);            // off the recurrent chain: it depends on saved values only
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
 #pragma unroll
-    for (int u = 0; u < X_H; ++u) s = fmaf(w[u], ds[blk * X_H + u], s);
-    part[blk][k] = s;
+    for (int u = 0; u < X_H; u += 4) {
+      s0 = fmaf(w[u], ds[blk * X_H + u], s0); s1 = fmaf(w[u + 1], ds[blk * X_H + u + 1], s1);
+      s2 = fmaf(w[u + 2], ds[blk * X_H + u + 2], s2); s3 = fmaf(w[u + 3], ds[blk * X_H + u + 3], s3);
+    }
+    part[blk][k] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (tid < X_H) {
-      const float dh = dh_in[(r0 + t) * X_H + tid] + ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]));
-      const float* gr = gates + (r0 + t) * X_G;
-      const float gi = gr[tid], gf = gr[X_H + tid], gg = gr[2 * X_H + tid], go = gr[3 * X_H + tid];
-      const float ct = cst[(r0 + t) * X_H + tid];
-      const float cprev = t > 0 ? cst[(r0 + t - 1) * X_H + tid] : 0.0f;
-      const float tc = tanhf(ct);
+      const float dh = dhi + ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]));
       const float dct = fmaf(dh * go, 1.0f - tc * tc, dc);
       const float di = dct * gg * gi * (1.0f - gi);
       const float df = dct * cprev * gf * (1.0f - gf);
