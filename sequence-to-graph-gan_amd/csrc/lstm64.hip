@@ -12,6 +12,7 @@
 
 #define X_H 64
 #define X_G 256
+#define X_PF 4         // steps of saved / precomputed rows in flight ahead of the recurrence
 
 // gates [rows, 256] (activated i, f, g, o), cst [rows, 64] (cell state), hout [rows, 64].
 // out_mask (optional, [rows, 64]): hout is ALSO written multiplied by it to hdrop (the next layer's input under
@@ -34,32 +35,58 @@ extern "C" __global__ __launch_bounds__(X_G) void s2g_k_lstm64_fwd(const float* 
   const size_t r0 = (size_t)n * T;
   const int q = j >> 6;                        // gate block: 0 i, 1 f, 2 g (tanh), 3 o
   float c = 0.0f;
-  float nxt = len > 0 ? pin[r0 * X_G + j] : 0.0f;
-  __syncthreads();
-  for (int t = 0; t < len; ++t) {
-    float a0 = nxt, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;             // four independent chains: issue-bound, not latency-bound
-    nxt = pin[(r0 + min(t + 1, len - 1)) * X_G + j];             // next step's input part, ahead of its use
-    const float4* h4 = reinterpret_cast<const float4*>(hs);
+  // the input part of the next X_PF steps sits in a register ring, refilled by UNCONDITIONAL loads from clamped
+  // rows right after a slot's use (one step ahead was not enough: the load's latency is about a step's time)
+  float nx[X_PF], mk[X_PF];
+  const int lastrow = max(len - 1, 0);
+  // the dropout multiplier travels in the same ring (every thread loads column j % 64: a load by the 64 cell
+  // threads alone would sit under a branch, where the compiler drains every load in flight); without a mask the
+  // loads read the input part instead and the value is not used
+  const bool has_mask = hdrop != nullptr && out_mask != nullptr;
+  const float* pm = has_mask ? out_mask + r0 * X_H + (j & 63) : pin + r0 * X_G + j;
+  const int sm = has_mask ? X_H : X_G;
 #pragma unroll
-    for (int k = 0; k < X_H / 4; ++k) {
-      const float4 hv = h4[k];
-      a0 = fmaf(w[4 * k], hv.x, a0); a1 = fmaf(w[4 * k + 1], hv.y, a1);
-      a2 = fmaf(w[4 * k + 2], hv.z, a2); a3 = fmaf(w[4 * k + 3], hv.w, a3);
+  for (int i = 0; i < X_PF; ++i) {
+    nx[i] = pin[(r0 + min(i, lastrow)) * X_G + j];
+    mk[i] = pm[(size_t)min(i, lastrow) * sm];
+  }
+  __syncthreads();
+  for (int base = 0; base < len; base += X_PF) {
+#pragma unroll
+    for (int i = 0; i < X_PF; ++i) {
+      const int t = base + i;
+      float a0 = nx[i], a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;         // four independent chains: issue-bound, not latency-bound
+      const float mkt = mk[i];
+      // the up to X_PF - 1 steps past the end run on clamped inputs and store nothing: a branch around the step
+      // (with its barriers) makes the compiler wait for every load in flight at the join
+      const bool live = t < len;
+      const float4* h4 = reinterpret_cast<const float4*>(hs);
+#pragma unroll
+      for (int k = 0; k < X_H / 4; ++k) {
+        const float4 hv = h4[k];
+        a0 = fmaf(w[4 * k], hv.x, a0); a1 = fmaf(w[4 * k + 1], hv.y, a1);
+        a2 = fmaf(w[4 * k + 2], hv.z, a2); a3 = fmaf(w[4 * k + 3], hv.w, a3);
+      }
+      const float a = (a0 + a1) + (a2 + a3);
+      const float g = (q == 2) ? fast_tanh(a) : fast_sigmoid(a);
+      gs[j] = g;
+      if (live) gates[(r0 + t) * X_G + j] = g;
+      __syncthreads();
+      if (j < X_H) {
+        c = fmaf(gs[X_H + j], c, gs[j] * gs[2 * X_H + j]);
+        const float h = gs[3 * X_H + j] * fast_tanh(c);
+        hs[j] = h;
+        if (live) {
+          cst[(r0 + t) * X_H + j] = c;
+          hout[(r0 + t) * X_H + j] = h;
+          if (hdrop) hdrop[(r0 + t) * X_H + j] = has_mask ? h * mkt : h;
+        }
+      }
+      // refill after the slot's last use: it keeps its registers across iterations (no copies, no waits)
+      nx[i] = pin[(r0 + min(t + X_PF, lastrow)) * X_G + j];
+      mk[i] = pm[(size_t)min(t + X_PF, lastrow) * sm];
+      __syncthreads();
     }
-    const float a = (a0 + a1) + (a2 + a3);
-    const float g = (q == 2) ? fast_tanh(a) : fast_sigmoid(a);
-    gs[j] = g;
-    gates[(r0 + t) * X_G + j] = g;
-    __syncthreads();
-    if (j < X_H) {
-      c = fmaf(gs[X_H + j], c, gs[j] * gs[2 * X_H + j]);
-      const float h = gs[3 * X_H + j] * fast_tanh(c);
-      hs[j] = h;
-      cst[(r0 + t) * X_H + j] = c;
-      hout[(r0 + t) * X_H + j] = h;
-      if (hdrop) hdrop[(r0 + t) * X_H + j] = out_mask ? h * out_mask[(r0 + t) * X_H + j] : h;
-    }
-    __syncthreads();
   }
   // rows beyond the sequence: zeros (what pad_packed_sequence returns, and what the batched products must see)
   for (size_t e = (size_t)len * X_H + j; e < (size_t)T * X_H; e += X_G) {
@@ -93,50 +120,55 @@ extern "C" __global__ __launch_bounds__(X_G) void s2g_k_lstm64_bwd(const float* 
   // inside the cell section would put a memory round trip on every step's critical path); lanes >= 64 of the
   // first wave's siblings load too (harmless, same addresses modulo 64) so that no load sits under a branch
   const int u0 = tid & 63;
-  float n_dh = 0.f, n_gi = 0.f, n_gf = 0.f, n_gg = 0.f, n_go = 0.f, n_c = 0.f, n_cp = 0.f;
-  if (len > 0) {
-    const size_t r = r0 + len - 1;
-    n_dh = dh_in[r * X_H + u0];
-    n_gi = gates[r * X_G + u0]; n_gf = gates[r * X_G + X_H + u0];
-    n_gg = gates[r * X_G + 2 * X_H + u0]; n_go = gates[r * X_G + 3 * X_H + u0];
-    n_c = cst[r * X_H + u0];
-    n_cp = cst[(r0 + max(len - 2, 0)) * X_H + u0];
+  const int lastrow = max(len - 1, 0);
+  float n_dh[X_PF], n_gi[X_PF], n_gf[X_PF], n_gg[X_PF], n_go[X_PF], n_c[X_PF], n_cp[X_PF];
+#define X_FETCH(i, t_)                                                        \
+  {                                                                           \
+    const size_t r = r0 + min(max((t_), 0), lastrow);                         \
+    n_dh[i] = dh_in[r * X_H + u0];                                            \
+    n_gi[i] = gates[r * X_G + u0]; n_gf[i] = gates[r * X_G + X_H + u0];       \
+    n_gg[i] = gates[r * X_G + 2 * X_H + u0]; n_go[i] = gates[r * X_G + 3 * X_H + u0]; \
+    n_c[i] = cst[r * X_H + u0];                                               \
+    n_cp[i] = cst[(r0 + min(max((t_) - 1, 0), lastrow)) * X_H + u0];          \
   }
-  __syncthreads();
-  for (int t = len - 1; t >= 0; --t) {
-    const float dhi = n_dh, gi = n_gi, gf = n_gf, gg = n_gg, go = n_go, ct = n_c;
-    const float cprev = t > 0 ? n_cp : 0.0f;
-    {
-      const size_t r = r0 + max(t - 1, 0);
-      n_dh = dh_in[r * X_H + u0];
-      n_gi = gates[r * X_G + u0]; n_gf = gates[r * X_G + X_H + u0];
-      n_gg = gates[r * X_G + 2 * X_H + u0]; n_go = gates[r * X_G + 3 * X_H + u0];
-      n_c = n_cp;
-      n_cp = cst[(r0 + max(t - 2, 0)) * X_H + u0];
-    }
-    const float tc = fast_tanh(ct);            // off the recurrent chain: it depends on saved values only
-    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
 #pragma unroll
-    for (int u = 0; u < X_H; u += 4) {
-      s0 = fmaf(w[u], ds[blk * X_H + u], s0); s1 = fmaf(w[u + 1], ds[blk * X_H + u + 1], s1);
-      s2 = fmaf(w[u + 2], ds[blk * X_H + u + 2], s2); s3 = fmaf(w[u + 3], ds[blk * X_H + u + 3], s3);
+  for (int i = 0; i < X_PF; ++i) X_FETCH(i, len - 1 - i)
+  __syncthreads();
+  for (int base = 0; base < len; base += X_PF) {
+#pragma unroll
+    for (int i = 0; i < X_PF; ++i) {
+      const int t = len - 1 - (base + i);
+      const float dhi = n_dh[i], gi = n_gi[i], gf = n_gf[i], gg = n_gg[i], go = n_go[i], ct = n_c[i];
+      const float cprev = t > 0 ? n_cp[i] : 0.0f;
+      const bool live = t >= 0;                      // steps past the start run on clamped rows and store nothing
+      const float tc = fast_tanh(ct);                // off the recurrent chain: it depends on saved values only
+      float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+#pragma unroll
+      for (int u = 0; u < X_H; u += 4) {
+        s0 = fmaf(w[u], ds[blk * X_H + u], s0); s1 = fmaf(w[u + 1], ds[blk * X_H + u + 1], s1);
+        s2 = fmaf(w[u + 2], ds[blk * X_H + u + 2], s2); s3 = fmaf(w[u + 3], ds[blk * X_H + u + 3], s3);
+      }
+      part[blk][k] = (s0 + s1) + (s2 + s3);
+      __syncthreads();
+      if (tid < X_H) {
+        const float dh = dhi + ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]));
+        const float dct = fmaf(dh * go, 1.0f - tc * tc, dc);
+        const float di = dct * gg * gi * (1.0f - gi);
+        const float df = dct * cprev * gf * (1.0f - gf);
+        const float dg = dct * gi * (1.0f - gg * gg);
+        const float dO = dh * tc * go * (1.0f - go);
+        dc = dct * gf;
+        if (live) {
+          float* dr = delta + (r0 + t) * X_G;
+          dr[tid] = di; dr[X_H + tid] = df; dr[2 * X_H + tid] = dg; dr[3 * X_H + tid] = dO;
+        }
+        ds[tid] = di; ds[X_H + tid] = df; ds[2 * X_H + tid] = dg; ds[3 * X_H + tid] = dO;
+      }
+      X_FETCH(i, t - X_PF)      // after the slot's last use: it keeps its registers across iterations
+      __syncthreads();
     }
-    part[blk][k] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    if (tid < X_H) {
-      const float dh = dhi + ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]));
-      const float dct = fmaf(dh * go, 1.0f - tc * tc, dc);
-      const float di = dct * gg * gi * (1.0f - gi);
-      const float df = dct * cprev * gf * (1.0f - gf);
-      const float dg = dct * gi * (1.0f - gg * gg);
-      const float dO = dh * tc * go * (1.0f - go);
-      dc = dct * gf;
-      float* dr = delta + (r0 + t) * X_G;
-      dr[tid] = di; dr[X_H + tid] = df; dr[2 * X_H + tid] = dg; dr[3 * X_H + tid] = dO;
-      ds[tid] = di; ds[X_H + tid] = df; ds[2 * X_H + tid] = dg; ds[3 * X_H + tid] = dO;
-    }
-    __syncthreads();
   }
+#undef X_FETCH
   for (size_t e = (size_t)len * X_G + tid; e < (size_t)T * X_G; e += X_G) delta[r0 * X_G + e] = 0.0f;
 }
 
