@@ -426,7 +426,7 @@ def main():
                 table = json.load(f)
             for name in ("s2g_k_gumbel_softmax_fwd_v4<true>", "s2g_k_gumbel_softmax_fwd_v4<false>", "s2g_k_gumbel_softmax_bwd_v4",
                          "s2g_k_gp_interp", "s2g_k_one_hot", "s2g_k_gp_norm_penalty", "s2g_k_gp_dots", "s2g_k_adam",
-                         "s2g_k_dropout_mask_rng", "s2g_k_linear_wstream"):
+                         "s2g_k_dropout_mask_rng", "s2g_k_linear_wstream", "s2g_k_linear_wgrad_adam"):
                 t = table.get(name)
                 if t and "avg_ns" in t:
                     hbm_kernels[name] = {"bytes_per_launch": t["bytes_per_launch"], "avg_us": t["avg_ns"] / 1e3,

@@ -104,7 +104,7 @@ extern "C" __global__ __launch_bounds__(X_G) void s2g_k_lstm64_bwd(const float* 
                                                                    const float* __restrict__ gates,
                                                                    const float* __restrict__ cst,
                                                                    float* __restrict__ delta) {
-  __shared__ float ds[X_G];
+  __shared__ __attribute__((aligned(16))) float ds[X_G];
   __shared__ float part[4][X_H];
   const int n = blockIdx.x, tid = threadIdx.x;
   const int len = lengths ? min(max(lengths[n], 0), T) : T;
@@ -143,10 +143,12 @@ extern "C" __global__ __launch_bounds__(X_G) void s2g_k_lstm64_bwd(const float* 
       const bool live = t >= 0;                      // steps past the start run on clamped rows and store nothing
       const float tc = fast_tanh(ct);                // off the recurrent chain: it depends on saved values only
       float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+      const float4* d4 = reinterpret_cast<const float4*>(ds + blk * X_H);
 #pragma unroll
-      for (int u = 0; u < X_H; u += 4) {
-        s0 = fmaf(w[u], ds[blk * X_H + u], s0); s1 = fmaf(w[u + 1], ds[blk * X_H + u + 1], s1);
-        s2 = fmaf(w[u + 2], ds[blk * X_H + u + 2], s2); s3 = fmaf(w[u + 3], ds[blk * X_H + u + 3], s3);
+      for (int u = 0; u < X_H / 4; ++u) {
+        const float4 dv = d4[u];
+        s0 = fmaf(w[4 * u], dv.x, s0); s1 = fmaf(w[4 * u + 1], dv.y, s1);
+        s2 = fmaf(w[4 * u + 2], dv.z, s2); s3 = fmaf(w[4 * u + 3], dv.w, s3);
       }
       part[blk][k] = (s0 + s1) + (s2 + s3);
       __syncthreads();

@@ -57,6 +57,8 @@ ALGO = {   # kernel name in the profiler's trace -> (label, algorithmic bytes, n
     "s2g_k_gp_dots": ("penalty reduction", 8 * B * T * 200, "read delta, M2 delta"),
     "s2g_k_adam": ("Adam, 46 M parameters", 28 * 46_000_000, "read p, g, m, v; write p, m, v"),
     "s2g_k_dropout_mask_rng": ("dropout mask", 4 * 3 * B * T * 52, "write mask"),
+    "s2g_k_linear_wgrad_adam": ("output layer: weight gradient + Adam, 45.9 M parameters", 24 * 89600 * 512,
+                                "read W, m, v; write W, m, v (the gradient stays in registers / LDS)"),
 }
 
 
@@ -122,6 +124,11 @@ def main():
         8 * B * T * 200, "read delta, M2 delta")
     rec("s2g_k_adam (46 M parameters)", timeit(lambda: ops.adam(p, g, m, v, 2e-4, 0.5, 0.999, 1e-8, 3), reps=8), 28 * npar,
         "read p, g, m, v; write p, m, v")
+    Wl, ml, vl = p[:89600 * 512], m[:89600 * 512], v[:89600 * 512]
+    dyl, al = torch.randn(B, 89600, device=DEV) * 1e-3, torch.randn(B, 512, device=DEV)
+    rec("s2g_k_linear_wgrad_adam (output layer, 45.9 M parameters)",
+        timeit(lambda: ops.linear_wgrad_adam(dyl, al, Wl, ml, vl, 2e-4, 0.5, 0.999, 1e-8, 3), reps=8), 24 * 89600 * 512,
+        "read W, m, v; write W, m, v")
     rec("s2g_k_dropout_mask_rng", timeit(lambda: ops.dropout_mask_rng(3 * B * T, 0.3, DEV, rng)), 4 * mask.numel(),
         "write mask (includes torch's allocation of the output)")
     for k, r in res.items():
