@@ -148,7 +148,7 @@ class CriticEngine:
             self._m2_events = (torch.cuda.Event(), torch.cuda.Event())
         packed, ready = self._m2_events
         packed.record()
-        with torch.cuda.stream(side[1]):
+        with ops.on_stream(side[1]):
             side[1].wait_event(packed)
             ops.gemm_raw(ptr(self.W0p), self.Vp, 1, ptr(self.WT0), G4, 1, ptr(self.M2), G4, G4, G4, self.V)
             ready.record()
@@ -667,10 +667,10 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         else:
             gp_dots()
             fork.record()
-        with torch.cuda.stream(stream2):
+        with ops.on_stream(stream2):
             stream2.wait_event(fork)
             first_order(sc2)
-        with torch.cuda.stream(sweeps):
+        with ops.on_stream(sweeps):
             if not own:
                 stream_c.wait_event(fork)
             eng.timed("s2g_k_lstm2_tangent", lambda: eng.sweep_tangent(ws, drel, B, mrel, r_int, gp))
@@ -679,12 +679,12 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         # operand / product chain of stream2, which must be through before sweep D is
         small = eng.stream_g if eng.stream_g is not None else stream2
         join_g, after_d = eng._iter_events
-        with torch.cuda.stream(small):
+        with ops.on_stream(small):
             small.wait_event(fork)
             head_losses()
             first_order_sums(sc2)
             join_g.record()
-        with torch.cuda.stream(stream2):
+        with ops.on_stream(stream2):
             stream2.wait_event(after_c)
             _wgrad_launch(eng, built, 1)
             _wgrad_reduce(eng, built, early=True)
@@ -698,13 +698,13 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
             # sweep C (308 against 217 us); beside the phase-1 products both crawl (134 + 144 us under sweep D
             # instead of 55 + 80 one after the other) -- the step time is the same either way, but one after the
             # other they finish well before sweep D does and leave the last products alone on the chip.
-            with torch.cuda.stream(eng.stream_g):
+            with ops.on_stream(eng.stream_g):
                 prefetch(lambda: eng.stream_g.wait_event(join))
         if idle is not None and own:
-            with torch.cuda.stream(stream_c):      # free while the sweeps run on the caller's stream
+            with ops.on_stream(stream_c):      # free while the sweeps run on the caller's stream
                 stream_c.wait_event(fork)
                 idle()
-        with torch.cuda.stream(sweeps):
+        with ops.on_stream(sweeps):
             eng.timed("s2g_k_lstm2_bwd2", lambda: eng.sweep_bwd2(ws, drel, B, Tw, mrel, r_int, bsum=ws["bsumD"]))
             after_d.record()
         if idle is not None and not own:
@@ -713,7 +713,7 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
             cur.wait_event(after_d)
         cur.wait_event(join)
         _wgrad_launch(eng, built, 2)          # (join_g is covered by join_c below: stream_c waits for it first)
-        with torch.cuda.stream(stream_c):
+        with ops.on_stream(stream_c):
             if own:
                 stream_c.wait_event(after_d)
             stream_c.wait_event(join_g)      # the first-order bias sums and fc gradients these accumulate onto
@@ -772,7 +772,7 @@ def critic_forward_backward_fake(eng: CriticEngine, fake: torch.Tensor, labels: 
     if side is not None:
         fwd_done, vals_done = torch.cuda.Event(), torch.cuda.Event()
         fwd_done.record()
-        with torch.cuda.stream(side[1]):          # beside the reverse sweep
+        with ops.on_stream(side[1]):          # beside the reverse sweep
             side[1].wait_event(fwd_done)
             loss_values()
             vals_done.record()

@@ -22,6 +22,29 @@ def stream_ptr() -> int:
     return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
+class on_stream:
+    """`with on_stream(s):` makes torch stream `s` current, like torch.cuda.stream(s), through the C-level
+    getter / setter only: the torch context manager costs ~10 us of Python per use (device-index lookups), and a
+    critic iteration enters nine of them.  s = None: no change."""
+    __slots__ = ("s", "prev")
+
+    def __init__(self, s):
+        self.s = s
+
+    def __enter__(self):
+        s = self.s
+        if s is not None:
+            self.prev = torch._C._cuda_getCurrentStream(s.device_index)
+            torch._C._cuda_setStream(stream_id=s.stream_id, device_index=s.device_index, device_type=s.device_type)
+        return s
+
+    def __exit__(self, *exc):
+        if self.s is not None:
+            sid, dev, typ = self.prev
+            torch._C._cuda_setStream(stream_id=sid, device_index=dev, device_type=typ)
+        return False
+
+
 def _chk(t: torch.Tensor, dtype=torch.float32, name="tensor"):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise S2GError(f"{name}: expected a CUDA/HIP tensor (this implementation has no CPU path)")

@@ -107,7 +107,7 @@ class WGANGPTrainer:
             self._stream = torch.cuda.Stream(device=self.device)
         own = self._stream
         own.wait_stream(cur)
-        with torch.cuda.stream(own):
+        with ops.on_stream(own):
             yield
         cur.wait_stream(own)
 
@@ -314,7 +314,7 @@ class WGANGPTrainer:
                 ready = torch.cuda.Event()
                 ready.record()
                 keep.extend((dl2, a3))        # allocated on this stream, read on the other: alive until the join
-                with torch.cuda.stream(stream_s):
+                with ops.on_stream(stream_s):
                     stream_s.wait_event(ready)
                     last_layer_update(dl2, a3, self.D.cu_masked)
                     done.record()
