@@ -21,7 +21,9 @@
 #include "s2g_common.h"
 
 #define PF 6
-#define PFD 4   // ring depth of sweep D's cell waves (5 saved tensors per step)
+#ifndef PFD
+#define PFD 6   // ring depth of sweep D's cell waves (5 saved tensors per step)
+#endif
 #define BWD_THREADS 512
 #define DVEC 224   // LDS delta vector: 8 slices of 25 gate rows, each padded to 28 floats
 #define DPP_ROW_SHL(n) (0x100 + (n))

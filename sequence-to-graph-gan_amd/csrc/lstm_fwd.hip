@@ -24,6 +24,9 @@
 #include "s2g_common.h"
 
 #define PF 6
+#ifndef PFC
+#define PFC 6                  // ring depth of sweep C's cell waves
+#endif
 #define FWD_THREADS 512
 #define HV 56                  // LDS state vector: 2 slices of 25 units, each padded to 28 floats
 #define FWD_LDS_FLOATS 864     // h0buf[2][HV] h1buf[2][HV] ybuf[2][64] p1buf[2][256]
@@ -380,9 +383,9 @@ extern "C" __global__ __launch_bounds__(FWD_THREADS) void s2g_k_lstm2_tangent(
   const int hp = pos25(uc), yp = pos13(uc);
   __syncthreads();
 
-  float4 rg[PF];
-  float2 rx[PF], rc[PF];
-  float mk[PF];
+  float4 rg[PFC];
+  float2 rx[PFC], rc[PFC];
+  float mk[PFC];
 #define ISSUE_C(j, t)                                                        \
   {                                                                          \
     const int tc_ = max(min((t), len - 1), 0);                               \
@@ -391,9 +394,9 @@ extern "C" __global__ __launch_bounds__(FWD_THREADS) void s2g_k_lstm2_tangent(
     rx[j] = *reinterpret_cast<const float2*>(px + (unsigned)(tc_ * sx) + lo2);     \
     mk[j] = (pm + (unsigned)(tc_ * sm))[uc];                                       \
   }
-  // ring slot tau % PF holds step tau - lag
+  // ring slot tau % PFC holds step tau - lag
 #pragma unroll
-  for (int j = 0; j < PF; ++j) ISSUE_C(j, j - lag)
+  for (int j = 0; j < PFC; ++j) ISSUE_C(j, j - lag)
 
   // gp_partial (optional): Xdot holds the UNSCALED projected direction M2 delta of the gradient
   // penalty; its per-sample factor comes from the four partial sums of |g|^2 (s2g_k_gp_dots), so no
@@ -402,9 +405,9 @@ extern "C" __global__ __launch_bounds__(FWD_THREADS) void s2g_k_lstm2_tangent(
       gp_partial ? gp_coef_from_partials(gp_partial + 4 * blockIdx.x, gp_upstream, gp_n_batch) : 1.0f;
   float cd = 0.0f;      // cdot carried
   float cprev = 0.0f;   // primal c_{t-1} carried
-  for (int base = 0; base < nit; base += PF) {
+  for (int base = 0; base < nit; base += PFC) {
 #pragma unroll
-    for (int j = 0; j < PF; ++j) {
+    for (int j = 0; j < PFC; ++j) {
       const int tau = base + j;
       if (tau < nit) {
         const int t = tau - lag;
@@ -437,7 +440,7 @@ extern "C" __global__ __launch_bounds__(FWD_THREADS) void s2g_k_lstm2_tangent(
         }
         __syncthreads();
       }
-      ISSUE_C(j, tau + PF - lag)     // refill after the slot's last use: it keeps its registers
+      ISSUE_C(j, tau + PFC - lag)     // refill after the slot's last use: it keeps its registers
     }
   }
 }
