@@ -1,7 +1,8 @@
 // LSTM sweeps for the weight-clipping WGAN variant (reference wgan.py: nn.LSTM(64, 64, num_layers) in
 // Generator :58 and Discriminator :100, hidden_dim = 64) and its attention pooling (wgan.py:75-89).
-// One layer per launch over all its time steps, one workgroup of 256 threads per sequence: thread j owns gate
-// row j (torch order: i | f | g | o blocks of 64) with its 64 recurrent weights in registers; the input part
+// One layer per launch over all its time steps, one workgroup of 256 threads per sequence: a thread owns one
+// gate row (forward: the four gates of a unit in one quad) / one gate block's slice of a column (reverse) with its
+// 64 recurrent weights in registers; the input part
 // x_t W_ih^T + b_ih + b_hh of every step is a batched GEMM done beforehand (it does not depend on the
 // recurrence), and the weight gradients are batched GEMMs over the saved gate gradients afterwards.
 // Rows: sequence n owns rows [n * rows_per_seq, n * rows_per_seq + len_n) of every [rows, .] buffer; rows at or
@@ -17,6 +18,9 @@
 // gates [rows, 256] (activated i, f, g, o), cst [rows, 64] (cell state), hout [rows, 64].
 // out_mask (optional, [rows, 64]): hout is ALSO written multiplied by it to hdrop (the next layer's input under
 // nn.LSTM's inter-layer dropout); the recurrence itself uses the undropped h.
+// Thread j = (unit j / 4, gate j % 4): the four gates of a unit sit in one quad, so the cell update needs no LDS
+// (DPP quad broadcasts; every lane of the quad advances the same c) and a step has ONE barrier: h is double
+// buffered in LDS.
 extern "C" __global__ __launch_bounds__(X_G) void s2g_k_lstm64_fwd(const float* __restrict__ pin,
                                                                    const float* __restrict__ whh,
                                                                    const int* __restrict__ lengths, int T,
@@ -24,30 +28,31 @@ extern "C" __global__ __launch_bounds__(X_G) void s2g_k_lstm64_fwd(const float* 
                                                                    float* __restrict__ hout,
                                                                    const float* __restrict__ out_mask,
                                                                    float* __restrict__ hdrop) {
-  __shared__ __attribute__((aligned(16))) float hs[X_H];
-  __shared__ float gs[X_G];
+  __shared__ __attribute__((aligned(16))) float hs[2][X_H];
   const int n = blockIdx.x, j = threadIdx.x;
+  const int unit = j >> 2, q = j & 3;          // gate block q: 0 i, 1 f, 2 g (tanh), 3 o
+  const int row = q * X_H + unit;              // torch gate row
   const int len = lengths ? min(max(lengths[n], 0), T) : T;
   float w[X_H];
 #pragma unroll
-  for (int k = 0; k < X_H; ++k) w[k] = whh[j * X_H + k];
-  if (j < X_H) hs[j] = 0.0f;
+  for (int k = 0; k < X_H; ++k) w[k] = whh[row * X_H + k];
+  if (j < 2 * X_H) hs[0][j] = 0.0f;
   const size_t r0 = (size_t)n * T;
-  const int q = j >> 6;                        // gate block: 0 i, 1 f, 2 g (tanh), 3 o
+  // sigma(a) and tanh(a) = 2 sigma(2a) - 1 share one exp / rcp: per-lane constants instead of a branch
+  const float kact = (q == 2) ? -2.8853900817779268f : -1.4426950408889634f;
+  const float actA = (q == 2) ? 2.0f : 1.0f, actB = (q == 2) ? -1.0f : 0.0f;
   float c = 0.0f;
   // the input part of the next X_PF steps sits in a register ring, refilled by UNCONDITIONAL loads from clamped
-  // rows right after a slot's use (one step ahead was not enough: the load's latency is about a step's time)
+  // rows after a slot's last use (it keeps its registers: no copies, no waits); the dropout multiplier travels
+  // in the same ring (without a mask the loads read the input part instead and the value is not used)
   float nx[X_PF], mk[X_PF];
   const int lastrow = max(len - 1, 0);
-  // the dropout multiplier travels in the same ring (every thread loads column j % 64: a load by the 64 cell
-  // threads alone would sit under a branch, where the compiler drains every load in flight); without a mask the
-  // loads read the input part instead and the value is not used
   const bool has_mask = hdrop != nullptr && out_mask != nullptr;
-  const float* pm = has_mask ? out_mask + r0 * X_H + (j & 63) : pin + r0 * X_G + j;
+  const float* pm = has_mask ? out_mask + r0 * X_H + unit : pin + r0 * X_G + row;
   const int sm = has_mask ? X_H : X_G;
 #pragma unroll
   for (int i = 0; i < X_PF; ++i) {
-    nx[i] = pin[(r0 + min(i, lastrow)) * X_G + j];
+    nx[i] = pin[(r0 + min(i, lastrow)) * X_G + row];
     mk[i] = pm[(size_t)min(i, lastrow) * sm];
   }
   __syncthreads();
@@ -55,12 +60,11 @@ extern "C" __global__ __launch_bounds__(X_G) void s2g_k_lstm64_fwd(const float* 
 #pragma unroll
     for (int i = 0; i < X_PF; ++i) {
       const int t = base + i;
-      float a0 = nx[i], a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;         // four independent chains: issue-bound, not latency-bound
-      const float mkt = mk[i];
       // the up to X_PF - 1 steps past the end run on clamped inputs and store nothing: a branch around the step
-      // (with its barriers) makes the compiler wait for every load in flight at the join
+      // (with its barrier) makes the compiler wait for every load in flight at the join
       const bool live = t < len;
-      const float4* h4 = reinterpret_cast<const float4*>(hs);
+      float a0 = nx[i], a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;         // four independent chains: issue-bound, not latency-bound
+      const float4* h4 = reinterpret_cast<const float4*>(hs[t & 1]);
 #pragma unroll
       for (int k = 0; k < X_H / 4; ++k) {
         const float4 hv = h4[k];
@@ -68,22 +72,20 @@ extern "C" __global__ __launch_bounds__(X_G) void s2g_k_lstm64_fwd(const float* 
         a2 = fmaf(w[4 * k + 2], hv.z, a2); a3 = fmaf(w[4 * k + 3], hv.w, a3);
       }
       const float a = (a0 + a1) + (a2 + a3);
-      const float g = (q == 2) ? fast_tanh(a) : fast_sigmoid(a);
-      gs[j] = g;
-      if (live) gates[(r0 + t) * X_G + j] = g;
-      __syncthreads();
-      if (j < X_H) {
-        c = fmaf(gs[X_H + j], c, gs[j] * gs[2 * X_H + j]);
-        const float h = gs[3 * X_H + j] * fast_tanh(c);
-        hs[j] = h;
+      const float g = fmaf(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(kact * a)), actA, actB);
+      if (live) gates[(r0 + t) * X_G + row] = g;
+      const float gi = quad_bcast<0>(g), gf = quad_bcast<1>(g), gg = quad_bcast<2>(g), go = quad_bcast<3>(g);
+      c = fmaf(gf, c, gi * gg);
+      const float h = go * fast_tanh(c);
+      if (q == 0) {
+        hs[(t + 1) & 1][unit] = h;
         if (live) {
-          cst[(r0 + t) * X_H + j] = c;
-          hout[(r0 + t) * X_H + j] = h;
-          if (hdrop) hdrop[(r0 + t) * X_H + j] = has_mask ? h * mkt : h;
+          cst[(r0 + t) * X_H + unit] = c;
+          hout[(r0 + t) * X_H + unit] = h;
+          if (hdrop) hdrop[(r0 + t) * X_H + unit] = has_mask ? h * mk[i] : h;
         }
       }
-      // refill after the slot's last use: it keeps its registers across iterations (no copies, no waits)
-      nx[i] = pin[(r0 + min(t + X_PF, lastrow)) * X_G + j];
+      nx[i] = pin[(r0 + min(t + X_PF, lastrow)) * X_G + row];
       mk[i] = pm[(size_t)min(t + X_PF, lastrow) * sm];
       __syncthreads();
     }
