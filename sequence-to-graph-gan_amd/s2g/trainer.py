@@ -33,6 +33,9 @@ def dropout_mask(rows: int, p: float, device, rng: ops.DeviceRng) -> Optional[to
     return ops.dropout_mask_rng(rows, p, device, rng)
 
 
+_OWN_STREAMS: Dict[int, torch.cuda.Stream] = {}
+
+
 class WGANGPTrainer:
     def __init__(self, vocab: int, gen_seq_len: int, device, lr: float = 2e-4, b1: float = 0.5, b2: float = 0.999,
                  lambda_gp: float = 10.0, tau: float = 0.5, hard: bool = False, n_critic: int = 5,
@@ -104,7 +107,11 @@ class WGANGPTrainer:
             yield
             return
         if self._stream is None:
-            self._stream = torch.cuda.Stream(device=self.device)
+            # one non-blocking stream per device for every trainer of the process (four hardware queues in all)
+            idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+            if idx not in _OWN_STREAMS:
+                _OWN_STREAMS[idx] = torch.cuda.Stream(device=self.device)
+            self._stream = _OWN_STREAMS[idx]
         own = self._stream
         own.wait_stream(cur)
         with ops.on_stream(own):

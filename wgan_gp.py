@@ -335,8 +335,11 @@ def train_wgan(generator, discriminator, optimizer_G, optimizer_D, train_dataloa
             cur = upload(next(it, None))
             zu = draw_zu(cur)
             i = 0
+            after_next, have_after_next = None, False
             while cur is not None:
-                nxt = upload(next(it, None))            # the loader is read one batch ahead
+                # the loader is read one batch ahead (two around a loss print, see below)
+                nxt = after_next if have_after_next else upload(next(it, None))
+                have_after_next = False
                 gen_now = i % opt.n_critic == 0
                 alpha = draw_alpha(cur)
                 U2 = draw_u2(cur) if gen_now else None
@@ -351,6 +354,9 @@ def train_wgan(generator, discriminator, optimizer_G, optimizer_D, train_dataloa
                 if gen_now:
                     # (the output layer's update may still run on the side stream: the next forward waits for it)
                     tr.generator_step(U=U2, defer_join=True, keep_grads=False)
+                    # reading the losses waits for the GPU; whatever the host does between that moment and its next
+                    # launch is time the GPU idles, so the batch after next is checked and staged BEFORE the wait
+                    after_next, have_after_next = upload(next(it, None)), True
                     d_loss, g_loss = tr.losses().tolist()
                     print(
                         "[Epoch %d/%d] [Batch %d/%d] [D loss: %f] [G loss: %f]"
