@@ -244,8 +244,14 @@ class GeneratorEngine:
         call("s2g_lrelu_bwd", ptr(s["a1"]), ptr(da1), da1.numel(), stream_ptr())
         dx0 = torch.empty(B, LATENT, device=dev)
         ops.linear_bwd_dx(da1, p["model.0.weight"], dx0, sc)
-        ops.small_linear_grads([(dpre3, s["a2"], g["model.5.weight"], g["model.5.bias"]),
-                                (dpre2, s["a1"], g["model.2.weight"], g["model.2.bias"]),
-                                (da1, s["x0"], g["model.0.weight"], g["model.0.bias"])])
+        jobs = [(dpre3, s["a2"], g["model.5.weight"], g["model.5.bias"]),
+                (dpre2, s["a1"], g["model.2.weight"], g["model.2.bias"]),
+                (da1, s["x0"], g["model.0.weight"], g["model.0.bias"])]
+        if all(x.shape[1] % 4 == 0 for _, x, _, _ in jobs):
+            ops.small_linear_grads(jobs)
+        else:                                   # a latent size that is no multiple of 4: the generic products
+            for dyj, xj, dWj, dbj in jobs:
+                ops.linear_bwd_dw(dyj, xj, dWj, sc)
+                ops.colsum(dyj, B, dyj.shape[1], dyj.shape[1], dbj, sc)
         call("s2g_embed_mul_bwd", ptr(s["z"]), ptr(s["labels"]), ptr(dx0), ptr(g["label_embedding.weight"]), B,
              LATENT, self.n_classes, stream_ptr())
