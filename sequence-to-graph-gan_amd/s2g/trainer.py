@@ -171,6 +171,18 @@ class WGANGPTrainer:
                 torch.cuda.current_stream().wait_event(pre["done"])     # keep the generator's buffer updates ordered
             if z is None:
                 z = ops.rng_fill(torch.empty(B, LATENT, device=dev), 1, self.rng)
+            # this batch's own draws and sequence descriptors BEFORE the generator forward: after a generator
+            # update that forward waits (just before its last layer) for the output layer's update on the side
+            # stream, and whatever is enqueued ahead of the wait runs meanwhile instead of after it
+            if alpha is None:
+                alpha = ops.rng_fill(torch.empty(B, device=dev), 0, self.rng)
+            if mask is None and self.drop_rate > 0.0:
+                mask = dropout_mask(3 * B * max(T, self.L), self.drop_rate, dev, self.rng)
+            self._desc_cur ^= 1
+            if self._desc[self._desc_cur] is None or self._desc[self._desc_cur].numel() < 4 * B * 8:
+                self._desc[self._desc_cur] = torch.zeros(4 * B, 8, dtype=torch.int32, device=dev)
+            desc = self._desc[self._desc_cur]
+            batch_desc(lengths, alpha.reshape(-1), B, T, self.L, mask is not None, desc)
             fake = self.G.forward(z, labels, U, self.tau, self.hard, training=True, save=False,
                                   out=self._fake_buf(self._fake_cur, B))    # .detach(): no graph is kept
             self._join_generator(waited=True)     # the forward waited for a pending output-layer update
