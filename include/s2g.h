@@ -372,6 +372,9 @@ int s2g_wasserstein_loss(const float* dval, int B, float* dD, float* loss, void*
 /* p <- clamp(p, -clip, clip) (wgan.py:155-158) */
 int s2g_clamp(float* p, long n, float clip, void* stream);
 int s2g_mul_inplace(float* a, const float* b, long n, void* stream);
+/* a += b: the gradients of the fake pass (computed beside the real pass into a buffer of their own) join those of
+ * the real pass, as backward() accumulates them in one .grad (wgan.py:150) */
+int s2g_add_inplace(float* a, const float* b, long n, void* stream);
 
 /* ---- sequence -> graph.  Node features of the transition graph of each token sequence, what
  * GraphEncoder.encode (graph_encoder.py:57-133) computes per sequence with networkx (graph_encoder.py:86-91):

@@ -413,3 +413,7 @@ extern "C" __global__ void s2g_k_mul_inplace(float* __restrict__ a, const float*
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) a[i] *= b[i];
 }
+extern "C" __global__ void s2g_k_add_inplace(float* __restrict__ a, const float* __restrict__ b, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] += b[i];
+}

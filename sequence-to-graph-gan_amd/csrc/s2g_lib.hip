@@ -633,6 +633,11 @@ int s2g_mul_inplace(float* a, const float* b, long n, void* stream) {
   hipLaunchKernelGGL(s2g_k_mul_inplace, dim3(cdiv(n, 256)), dim3(256), 0, ST(stream), a, b, n);
   return LAUNCH_OK();
 }
+int s2g_add_inplace(float* a, const float* b, long n, void* stream) {
+  if (!a || !b || n <= 0) return -1;
+  hipLaunchKernelGGL(s2g_k_add_inplace, dim3(cdiv(n, 256)), dim3(256), 0, ST(stream), a, b, n);
+  return LAUNCH_OK();
+}
 
 struct S2GAttn {        // mirrors include/s2g.h
   int N, H, T, D;

@@ -115,6 +115,7 @@ SIGNATURES = {
     "s2g_wasserstein_loss": [P, I, P, P, P],
     "s2g_clamp": [P, L, F, P],
     "s2g_mul_inplace": [P, P, L, P],
+    "s2g_add_inplace": [P, P, L, P],
     "s2g_attention_fwd": [P, P, P, P, P, P, P, ctypes.POINTER(S2GAttn), P],
     "s2g_attention_bwd": [P, P, P, P, P, P, P, P, P, P, P, ctypes.POINTER(S2GAttn), P],
     "s2g_graph_features": [P, P, I, I, I, P, P, P, L, P],

@@ -146,6 +146,8 @@ class ClipCriticEngine:
         self.stack = _LstmStack(self.params, layers, device)
         self.scratch = ops.Scratch(device)
         self.rng = ops.DeviceRng()
+        self.overlap = True           # critic_step: the fake pass on a second stream beside the real pass
+        self._side = None
 
     def load(self, state: Dict[str, torch.Tensor]) -> None:
         for k, v in self.params.views.items():
@@ -182,9 +184,10 @@ class ClipCriticEngine:
                      weights=weights, pooled=pooled, lstm=saved) if save else None
         return dval, state
 
-    def backward(self, st, dD: torch.Tensor, accumulate: bool) -> None:
-        """Adds (or writes, accumulate=False) the parameter gradients of sum_n dD[n] * D_n into self.grads."""
-        p, g, dev, sc = self.params.views, self.grads.views, self.device, self.scratch
+    def backward(self, st, dD: torch.Tensor, accumulate: bool, grads=None, scratch=None) -> None:
+        """Adds (or writes, accumulate=False) the parameter gradients of sum_n dD[n] * D_n into self.grads
+        (or `grads`, with `scratch` for the split-K slabs: a pass that runs beside another needs both of its own)."""
+        p, g, dev, sc = self.params.views, (grads or self.grads).views, self.device, scratch or self.scratch
         B, T, Tp, rows = st["B"], st["T"], st["Tp"], st["B"] * st["T"]
         dout = torch.empty(rows, HID, device=dev)
         dwc = torch.empty(B, HID, device=dev)
@@ -235,12 +238,38 @@ class ClipCriticEngine:
         if masks_fake == "draw":
             masks_fake = self.dropout_masks(B * fake.shape[1])
         dval = torch.empty(2 * B, device=dev)
-        _, s_real = self.forward(real, labels, lengths, Tp, masks_real, dval[:B])
-        _, s_fake = self.forward(fake, labels, None, fake.shape[1], masks_fake, dval[B:])
         dD, loss = torch.empty(2 * B, device=dev), torch.empty(1, device=dev)
-        call("s2g_wasserstein_loss", ptr(dval), B, ptr(dD), ptr(loss), stream_ptr())
-        self.backward(s_real, dD[:B], accumulate=False)
-        self.backward(s_fake, dD[B:], accumulate=True)
+        if self.overlap:
+            # The real pass is one workgroup per sequence for 1024 steps: half of the chip idles under it.  The fake
+            # pass (100 steps) runs beside it on a second stream, forward and backward, with gradients and split-K
+            # scratch of its own; the two gradient buffers are added at the end (one fixed order of additions).
+            if self._side is None:
+                self._side = (torch.cuda.Stream(device=dev), self.params.like(), ops.Scratch(dev),
+                              [torch.cuda.Event() for _ in range(4)])
+            side, grads2, scratch2, (e_in, e_fwd, e_loss, e_bwd) = self._side
+            cur = torch.cuda.current_stream()
+            e_in.record()
+            with ops.on_stream(side):
+                side.wait_event(e_in)
+                _, s_fake = self.forward(fake, labels, None, fake.shape[1], masks_fake, dval[B:])
+                e_fwd.record()
+            _, s_real = self.forward(real, labels, lengths, Tp, masks_real, dval[:B])
+            cur.wait_event(e_fwd)
+            call("s2g_wasserstein_loss", ptr(dval), B, ptr(dD), ptr(loss), stream_ptr())
+            e_loss.record()
+            with ops.on_stream(side):
+                side.wait_event(e_loss)
+                self.backward(s_fake, dD[B:], accumulate=False, grads=grads2, scratch=scratch2)
+                e_bwd.record()
+            self.backward(s_real, dD[:B], accumulate=False)
+            cur.wait_event(e_bwd)
+            call("s2g_add_inplace", ptr(self.grads.flat), ptr(grads2.flat), self.grads.total, stream_ptr())
+        else:
+            _, s_real = self.forward(real, labels, lengths, Tp, masks_real, dval[:B])
+            _, s_fake = self.forward(fake, labels, None, fake.shape[1], masks_fake, dval[B:])
+            call("s2g_wasserstein_loss", ptr(dval), B, ptr(dD), ptr(loss), stream_ptr())
+            self.backward(s_real, dD[:B], accumulate=False)
+            self.backward(s_fake, dD[B:], accumulate=True)
         g = self.grads.views
         for l in range(self.layers):                    # b_ih and b_hh enter the gates as a sum: one gradient
             g[f"lstm.bias_hh_l{l}"].copy_(g[f"lstm.bias_ih_l{l}"])
