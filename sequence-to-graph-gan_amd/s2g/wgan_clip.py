@@ -224,19 +224,28 @@ class ClipCriticEngine:
                 for _ in range(self.layers - 1)] + [None]
 
     # ------------------------------------------------------------------ the critic update
-    def critic_step(self, real: torch.Tensor, labels: torch.Tensor, lengths: torch.Tensor, Tp: int, fake: torch.Tensor,
+    def critic_step(self, real: torch.Tensor, labels: torch.Tensor, lengths: torch.Tensor, Tp: int, fake,
                     lr: float, b1: float, b2: float, clip: float, masks_real="draw", masks_fake="draw",
-                    eps: float = 1e-8, update: bool = True) -> torch.Tensor:
+                    eps: float = 1e-8, update: bool = True, fake_len: Optional[int] = None) -> torch.Tensor:
         """wgan.py:174-198 for one batch: D(real tokens), D(fake soft sequences of length 100), d_loss =
         -(mean D(real) - mean D(fake)), Adam, clamp to [-clip, clip].  Returns d_loss (1-element device tensor);
         self.grads holds the gradients.  masks_*: lists of [rows, 64] dropout multipliers per layer gap,
-        None (no dropout) or "draw" (device draws at self.dropout)."""
+        None (no dropout) or "draw" (device draws at self.dropout).
+        fake: the generator's output [B, Tf, V] (detached, wgan.py:185), or a callable returning it together with
+        fake_len = Tf: the generator's forward then runs on the second stream too, beside the real pass."""
         B = real.shape[0]
         dev = self.device
+        make_fake = fake if callable(fake) else None
+        if make_fake is not None:
+            if fake_len is None:
+                raise S2GError("critic_step: a callable `fake` needs fake_len")
+            if not self.overlap:
+                fake, make_fake = make_fake(), None
+        Tf = fake_len if make_fake is not None else fake.shape[1]
         if masks_real == "draw":
             masks_real = self.dropout_masks(B * real.shape[1])
         if masks_fake == "draw":
-            masks_fake = self.dropout_masks(B * fake.shape[1])
+            masks_fake = self.dropout_masks(B * Tf)
         dval = torch.empty(2 * B, device=dev)
         dD, loss = torch.empty(2 * B, device=dev), torch.empty(1, device=dev)
         if self.overlap:
@@ -251,6 +260,8 @@ class ClipCriticEngine:
             e_in.record()
             with ops.on_stream(side):
                 side.wait_event(e_in)
+                if make_fake is not None:
+                    fake = make_fake()
                 _, s_fake = self.forward(fake, labels, None, fake.shape[1], masks_fake, dval[B:])
                 e_fwd.record()
             _, s_real = self.forward(real, labels, lengths, Tp, masks_real, dval[:B])

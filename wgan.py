@@ -152,12 +152,13 @@ class CWGAN(nn.Module):
         B = labels.size(0)
         noise = torch.randint(0, self.generator.vocab_size, size=(B, self.generator.latent_dim)).to(dev)     # :183
         # the reference passes `hard` in the position of `anneal_tau` (:185 against :63): hard sampling is never on
-        gen_data = self.generator(noise, labels, tau, hard)
+        gen_data = lambda: self.generator(noise, labels, tau, hard)      # noqa: E731  (runs beside the real pass)
         g = self.d_optimizer.param_groups[0]
         return D.critic_step(sequences.to(torch.int32).to(dev).contiguous(), labels, lengths.to(torch.int32).to(dev),
                              int(lengths.max()), gen_data, g["lr"], g["betas"][0], g["betas"][1], self.clip_value,
                              masks_real="draw" if self.discriminator.training else None,
-                             masks_fake="draw" if self.discriminator.training else None, eps=g["eps"])
+                             masks_fake="draw" if self.discriminator.training else None, eps=g["eps"],
+                             fake_len=noise.shape[1])
 
     def train_step(self, train_dataloader, tau, hard):
         from tqdm import tqdm
