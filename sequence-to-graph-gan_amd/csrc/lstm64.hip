@@ -296,13 +296,24 @@ extern "C" __global__ __launch_bounds__(256) void s2g_k_attnpool_fwd(float* __re
   const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const size_t r0 = (size_t)n * T;
   const float wk = wc[lane];
-  for (int t = wave; t < Tp; t += 4) {
-    const float a = tanhf(pre[(r0 + t) * X_H + lane]);
-    pre[(r0 + t) * X_H + lane] = a;
-    float s = wk * a;
+  // (the row loops are unrolled eight deep so that eight rows' loads are in flight together: one row at a time,
+  // every iteration paid a memory round trip)
+  for (int tb = wave; tb < Tp; tb += 32) {
+    float v[8];
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
-    if (lane == 0) sc[t] = s;
+    for (int j = 0; j < 8; ++j) v[j] = pre[(r0 + min(tb + 4 * j, Tp - 1)) * X_H + lane];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int t = tb + 4 * j;
+      if (t < Tp) {
+        const float a = tanhf(v[j]);
+        pre[(r0 + t) * X_H + lane] = a;
+        float s = wk * a;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
+        if (lane == 0) sc[t] = s;
+      }
+    }
   }
   __syncthreads();
   if (wave == 0) {
@@ -318,6 +329,7 @@ extern "C" __global__ __launch_bounds__(256) void s2g_k_attnpool_fwd(float* __re
   }
   __syncthreads();
   float acc = 0.0f;
+#pragma unroll 8
   for (int t = wave; t < Tp; t += 4) {
     const float wgt = expf(sc[t] - stat[0]) * stat[1];
     if (lane == 0) weights[(size_t)n * T + t] = wgt;
@@ -349,11 +361,20 @@ extern "C" __global__ __launch_bounds__(256) void s2g_k_attnpool_bwd(float* __re
   const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const size_t r0 = (size_t)n * T;
   const float dp = dD[n] * wl[lane];                       // d(pooled)
-  for (int t = wave; t < Tp; t += 4) {
-    float s = dp * out[(r0 + t) * X_H + lane];
+  for (int tb = wave; tb < Tp; tb += 32) {
+    float ov[8];
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
-    if (lane == 0) dw[t] = s;
+    for (int j = 0; j < 8; ++j) ov[j] = out[(r0 + min(tb + 4 * j, Tp - 1)) * X_H + lane];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int t = tb + 4 * j;
+      if (t < Tp) {
+        float s = dp * ov[j];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
+        if (lane == 0) dw[t] = s;
+      }
+    }
   }
   __syncthreads();
   if (wave == 0) {
@@ -366,13 +387,24 @@ extern "C" __global__ __launch_bounds__(256) void s2g_k_attnpool_bwd(float* __re
   __syncthreads();
   const float wk = wc[lane];
   float acc = 0.0f;
-  for (int t = wave; t < Tp; t += 4) {
-    const float wgt = weights[(size_t)n * T + t];
-    const float dsc = wgt * (dw[t] - dot_s);               // softmax backward
-    const float a = a_dpre[(r0 + t) * X_H + lane];
-    acc = fmaf(dsc, a, acc);                               // d(wc)
-    a_dpre[(r0 + t) * X_H + lane] = dsc * wk * (1.0f - a * a);
-    dout[(r0 + t) * X_H + lane] = wgt * dp;
+  for (int tb = wave; tb < Tp; tb += 32) {
+    float av[8], wv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int tc = min(tb + 4 * j, Tp - 1);
+      av[j] = a_dpre[(r0 + tc) * X_H + lane];
+      wv[j] = weights[(size_t)n * T + tc];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int t = tb + 4 * j;
+      if (t < Tp) {
+        const float dsc = wv[j] * (dw[t] - dot_s);             // softmax backward
+        acc = fmaf(dsc, av[j], acc);                           // d(wc)
+        a_dpre[(r0 + t) * X_H + lane] = dsc * wk * (1.0f - av[j] * av[j]);
+        dout[(r0 + t) * X_H + lane] = wv[j] * dp;
+      }
+    }
   }
   for (int t = Tp + wave; t < T; t += 4) {                 // rows the pooling never saw
     a_dpre[(r0 + t) * X_H + lane] = 0.0f;
