@@ -199,7 +199,7 @@ extern "C" __global__ void s2g_k_embed_concat(const int* __restrict__ tokens, co
 // 32-thread groups walks a quarter of them in ascending order, adding row r's 32 columns into its own [V][32] table in
 // LDS at the row's token (the 32 threads of a group own distinct columns); the four tables are added in order and the
 // chunk's table goes to part[chunk][V * 32].  Stage 2 (s2g_k_embed_grad_final) adds the chunks in ascending order.
-#define EG_CHUNK 1024
+#define EG_CHUNK 512
 #define EG_GROUPS 4
 extern "C" __global__ __launch_bounds__(32 * EG_GROUPS) void s2g_k_embed_grad_tokens_part(
     const int* __restrict__ tokens, const int* __restrict__ lengths, int T, long rows, int V,

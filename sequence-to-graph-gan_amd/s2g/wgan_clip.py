@@ -11,7 +11,7 @@ import torch
 
 from . import ops
 from .critic import FlatBuffer
-from .lib import S2GError, call
+from .lib import S2GError, call, get
 from .ops import ptr, stream_ptr
 
 HID, G4X, EMB = 64, 256, 32
@@ -210,7 +210,7 @@ class ClipCriticEngine:
             lens = st["lengths"]
             if lens is None:
                 lens = torch.full((B,), T, dtype=torch.int32, device=dev)
-            part = sc.get(((rows + 1023) // 1024) * self.V * 32)       # = s2g_embed_grad_tokens_scratch(rows, V)
+            part = sc.get(int(get().s2g_embed_grad_tokens_scratch(rows, self.V)))
             call("s2g_embed_grad_tokens", ptr(st["seq"]), ptr(lens), T, rows, self.V, ptr(dx), ptr(ge), int(accumulate),
                  ptr(part), stream_ptr())
         part = sc.get(B * 32)

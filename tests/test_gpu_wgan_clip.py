@@ -137,7 +137,7 @@ def test_embedding_gradients_match_index_add(B, T, V):
     ref_l = torch.zeros(2, 32, dtype=torch.float64).index_add_(0, labels, per_seq)
     L = get()
     n_part = L.s2g_embed_grad_tokens_scratch(B * T, V)
-    assert n_part == ((B * T + 1023) // 1024) * V * 32
+    assert n_part >= V * 32 and n_part % (V * 32) == 0          # one [V, 32] table per chunk of rows
     part = torch.empty(max(n_part, B * 32), device=DEV)
     de = torch.full((V, 32), 0.5, device=DEV)
     dl = torch.full((2, 32), 0.25, device=DEV)
