@@ -342,6 +342,23 @@ int s2g_attention_bwd(const float* Q, const float* K, const float* V, const floa
  * out_mask / hdrop (optional): hdrop = hout * out_mask, the next layer's input under nn.LSTM's dropout. */
 int s2g_lstm64_fwd(const float* pin, const float* whh, const int* lengths, int nseq, int T, float* gates, float* cst,
                    float* hout, const float* out_mask, float* hdrop, void* stream);
+/* All layers of that stack in one sweep (layers = 2 or 3; nn.LSTM(64, 64, num_layers) of wgan.py:58, 100): layer
+ * l + 1 runs one step behind layer l and takes its input mask[l] * h_l (nn.LSTM's inter-layer dropout, mask NULL =
+ * none) through on-chip memory, so only layer 0 needs the batched input product pin0.  Per layer: whh [256, 64];
+ * from layer 1 on wih [256, 64] and bsum [256] = b_ih + b_hh; outputs as s2g_lstm64_fwd writes them, each
+ * optional (NULL = not stored) except the top layer's hout. */
+typedef struct S2GLstm64Stack {
+  const float* pin0;
+  const float* whh[3];
+  const float* wih[3];
+  const float* bsum[3];
+  float* gates[3];
+  float* cst[3];
+  float* hout[3];
+  const float* mask[3];
+  float* hdrop[3];
+} S2GLstm64Stack;
+int s2g_lstm64_stack_fwd(const S2GLstm64Stack* st, int layers, const int* lengths, int nseq, int T, void* stream);
 /* its autograd: dh_in [rows, 64] = gradient reaching every h_t from above -> delta [rows, 256], the gradient of
  * the gate pre-activations (zeros beyond the length); weight / input gradients are batched products of delta. */
 int s2g_lstm64_bwd(const float* dh_in, const float* whh, const int* lengths, int nseq, int T, const float* gates,

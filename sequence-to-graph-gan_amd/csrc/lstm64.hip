@@ -97,6 +97,173 @@ extern "C" __global__ __launch_bounds__(X_G) void s2g_k_lstm64_fwd(const float* 
   }
 }
 
+// Lane q of a quad holds slice [16 q, 16 q + 16) of the vector and, as pairs, the matching 16 weights of each of the
+// unit's four gate rows: four 16-byte LDS reads per product instead of sixteen (every lane reading the whole
+// vector makes a step LDS-bandwidth bound: a 16-byte read of a full wave occupies the LDS for 8 cycles whatever
+// the addresses).
+__device__ __forceinline__ void x_slice_fma(const f2 (&w)[4][8], const float* slice, f2 (&p)[4]) {
+  const f4* v4 = reinterpret_cast<const f4*>(slice);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const f4 v = v4[k];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      p[g] = __builtin_elementwise_fma(w[g][2 * k], (f2){v.x, v.y}, p[g]);
+      p[g] = __builtin_elementwise_fma(w[g][2 * k + 1], (f2){v.z, v.w}, p[g]);
+    }
+  }
+}
+// p0..p3: this lane's partial sums of gates 0..3; returns to lane q the sum of gate q over the quad's four lanes
+__device__ __forceinline__ float quad_gate_sum(float p0, float p1, float p2, float p3, int q) {
+  const bool b0 = q & 1, b1 = q & 2;
+  const float a = (b0 ? p1 : p0) + dpp_mov<DPP_QUAD(1, 0, 3, 2)>(b0 ? p0 : p1);
+  const float b = (b0 ? p3 : p2) + dpp_mov<DPP_QUAD(1, 0, 3, 2)>(b0 ? p2 : p3);
+  return (b1 ? b : a) + dpp_mov<DPP_QUAD(2, 3, 0, 1)>(b1 ? a : b);
+}
+
+// All layers of the stack in one sweep (2 or 3 layers).  One workgroup per sequence, one group of 256 threads per
+// layer; at tick s group l runs time step s - l, so layer l + 1 follows layer l one step behind and the sweep
+// takes len + layers - 1 ticks instead of layers * len steps.  Group 0 is the single-layer kernel above (its
+// input part comes from the batched product); a thread of an upper group also holds its row of W_ih (128 weights
+// in registers) and adds W_ih x_t to the recurrent product, x_t = mask * h_t of the layer below, handed over
+// through LDS: the batched input products of the upper layers and their round trips through HBM disappear.
+// Every group executes the same number of barriers (ticks rounded up to a multiple of X_PF for all of them).
+struct S2GLstm64Stack {    // mirrors include/s2g.h
+  const float* pin0;        // [rows, 256] input part of layer 0 (x W_ih0^T + b_ih0 + b_hh0)
+  const float* whh[3];      // [256, 64] per layer
+  const float* wih[3];      // [256, 64], layers >= 1
+  const float* bsum[3];     // [256] b_ih + b_hh, layers >= 1
+  float* gates[3];          // [rows, 256] saved activated gates (optional: null = not saved)
+  float* cst[3];            // [rows, 64] saved cell states (optional)
+  float* hout[3];           // [rows, 64] outputs (optional below the top layer)
+  const float* mask[3];     // [rows, 64] dropout multiplier between layer l and l + 1 (optional)
+  float* hdrop[3];          // [rows, 64] mask * h: the saved input of layer l + 1 (optional)
+};
+
+template <int NL>
+__global__ __launch_bounds__(X_G * NL) void s2g_k_lstm64_stack_fwd(S2GLstm64Stack a, const int* __restrict__ lengths,
+                                                                   int T) {
+  __shared__ __attribute__((aligned(16))) float hs[NL][2][X_H];   // h of layer l, double buffered
+  __shared__ __attribute__((aligned(16))) float xs[NL][2][X_H];   // xs[l]: input of layer l + 1
+  const int n = blockIdx.x;
+  const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8), j = threadIdx.x & (X_G - 1);
+  const int unit = j >> 2, q = j & 3;
+  const int row = q * X_H + unit;
+  const int len = lengths ? min(max(lengths[n], 0), T) : T;
+  const int nticks = len > 0 ? ((len + NL - 1 + X_PF - 1) / X_PF) * X_PF : 0;
+  const size_t r0 = (size_t)n * T;
+  const float kact = (q == 2) ? -2.8853900817779268f : -1.4426950408889634f;
+  const float actA = (q == 2) ? 2.0f : 1.0f, actB = (q == 2) ? -1.0f : 0.0f;
+  const int lastrow = max(len - 1, 0);
+  for (int e = threadIdx.x; e < NL * 2 * X_H; e += X_G * NL) { (&hs[0][0][0])[e] = 0.0f; (&xs[0][0][0])[e] = 0.0f; }
+  float* __restrict__ gates = a.gates[grp];
+  float* __restrict__ cst = a.cst[grp];
+  float* __restrict__ hout = a.hout[grp];
+  float* __restrict__ hdrop = a.hdrop[grp];
+  const float* whh = a.whh[grp];
+  const bool feeds = grp + 1 < NL;                                // a layer above reads this group's output
+  const bool has_mask = feeds && a.mask[grp] != nullptr;
+  // the dropout multiplier of the next X_PF steps travels in a register ring (unconditional loads from clamped
+  // rows; without a mask the loads read a weight instead and the value is not used)
+  const float* pm = has_mask ? a.mask[grp] + r0 * X_H + unit : whh + row;
+  const int sm = has_mask ? X_H : 0;
+  float mk[X_PF];
+  float c = 0.0f;
+  if (grp == 0) {
+    f2 w[4][8];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) w[g][k] = *reinterpret_cast<const f2*>(whh + (g * X_H + unit) * X_H + 16 * q + 2 * k);
+    const float* __restrict__ pin = a.pin0;
+    float nx[X_PF];
+#pragma unroll
+    for (int i = 0; i < X_PF; ++i) {
+      nx[i] = pin[(r0 + min(i, lastrow)) * X_G + row];
+      mk[i] = pm[(size_t)min(i, lastrow) * sm];
+    }
+    __syncthreads();
+    for (int base = 0; base < nticks; base += X_PF) {
+#pragma unroll
+      for (int i = 0; i < X_PF; ++i) {
+        const int t = base + i;
+        const bool live = t < len;
+        f2 p[4] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
+        x_slice_fma(w, hs[0][t & 1] + 16 * q, p);
+        const float s = nx[i] + quad_gate_sum(p[0].x + p[0].y, p[1].x + p[1].y, p[2].x + p[2].y, p[3].x + p[3].y, q);
+        const float g = fmaf(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(kact * s)), actA, actB);
+        if (live && gates) gates[(r0 + t) * X_G + row] = g;
+        const float gi = quad_bcast<0>(g), gf = quad_bcast<1>(g), gg = quad_bcast<2>(g), go = quad_bcast<3>(g);
+        c = fmaf(gf, c, gi * gg);
+        const float h = go * fast_tanh(c);
+        if (q == 0) {
+          const float hx = has_mask ? h * mk[i] : h;
+          hs[0][(t + 1) & 1][unit] = h;
+          xs[0][t & 1][unit] = hx;
+          if (live) {
+            if (cst) cst[(r0 + t) * X_H + unit] = c;
+            if (hout) hout[(r0 + t) * X_H + unit] = h;
+            if (hdrop) hdrop[(r0 + t) * X_H + unit] = hx;
+          }
+        }
+        nx[i] = pin[(r0 + min(t + X_PF, lastrow)) * X_G + row];
+        mk[i] = pm[(size_t)min(t + X_PF, lastrow) * sm];
+        __syncthreads();
+      }
+    }
+  } else {
+    f2 wh[4][8], wi[4][8];
+    const float* wih = a.wih[grp];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        wh[g][k] = *reinterpret_cast<const f2*>(whh + (g * X_H + unit) * X_H + 16 * q + 2 * k);
+        wi[g][k] = *reinterpret_cast<const f2*>(wih + (g * X_H + unit) * X_H + 16 * q + 2 * k);
+      }
+    const float bias = a.bsum[grp][row];
+#pragma unroll
+    for (int i = 0; i < X_PF; ++i) mk[i] = pm[(size_t)min(max(i - grp, 0), lastrow) * sm];
+    __syncthreads();
+    for (int base = 0; base < nticks; base += X_PF) {
+#pragma unroll
+      for (int i = 0; i < X_PF; ++i) {
+        const int t = base + i - grp;                  // this layer's time step at this tick
+        const bool live = t >= 0 && t < len;
+        f2 ph[4] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
+        f2 px[4] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
+        x_slice_fma(wh, hs[grp][t & 1] + 16 * q, ph);
+        x_slice_fma(wi, xs[grp - 1][t & 1] + 16 * q, px);
+        const float s = bias + quad_gate_sum((ph[0].x + ph[0].y) + (px[0].x + px[0].y), (ph[1].x + ph[1].y) + (px[1].x + px[1].y),
+                                             (ph[2].x + ph[2].y) + (px[2].x + px[2].y), (ph[3].x + ph[3].y) + (px[3].x + px[3].y), q);
+        const float g = fmaf(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(kact * s)), actA, actB);
+        if (live && gates) gates[(r0 + t) * X_G + row] = g;
+        const float gi = quad_bcast<0>(g), gf = quad_bcast<1>(g), gg = quad_bcast<2>(g), go = quad_bcast<3>(g);
+        const float cn = fmaf(gf, c, gi * gg);
+        c = live ? cn : c;                             // before its first step the layer stays at c = 0, h = 0
+        const float h = live ? go * fast_tanh(cn) : 0.0f;
+        if (q == 0) {
+          const float hx = has_mask ? h * mk[i] : h;
+          hs[grp][(t + 1) & 1][unit] = h;
+          if (feeds) xs[grp][t & 1][unit] = hx;
+          if (live) {
+            if (cst) cst[(r0 + t) * X_H + unit] = cn;
+            if (hout) hout[(r0 + t) * X_H + unit] = h;
+            if (hdrop) hdrop[(r0 + t) * X_H + unit] = hx;
+          }
+        }
+        mk[i] = pm[(size_t)min(max(t + X_PF, 0), lastrow) * sm];
+        __syncthreads();
+      }
+    }
+  }
+  // rows beyond the sequence: zeros (what pad_packed_sequence returns, and what the batched products must see)
+  for (size_t e = (size_t)len * X_H + j; e < (size_t)T * X_H; e += X_G) {
+    if (hout) hout[r0 * X_H + e] = 0.0f;
+    if (hdrop) hdrop[r0 * X_H + e] = 0.0f;
+  }
+}
+
 // Reverse sweep of one layer.  dh_in [rows, 64]: gradient reaching h_t from above (the attention pooling or
 // the next layer's input gradient; already multiplied by that layer's dropout mask where one applies).
 // delta [rows, 256]: gradient wrt the gate pre-activations (rows beyond the length zeroed).

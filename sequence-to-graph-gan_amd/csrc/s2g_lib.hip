@@ -556,6 +556,20 @@ int s2g_lstm64_fwd(const float* pin, const float* whh, const int* lengths, int n
                      out_mask, hdrop);
   return LAUNCH_OK();
 }
+int s2g_lstm64_stack_fwd(const S2GLstm64Stack* st, int layers, const int* lengths, int nseq, int T, void* stream) {
+  if (!st || (layers != 2 && layers != 3) || nseq <= 0 || T <= 0 || !st->pin0) return -1;
+  for (int l = 0; l < layers; ++l) {
+    if (!st->whh[l]) return -1;
+    if (l > 0 && (!st->wih[l] || !st->bsum[l])) return -1;
+    if (st->mask[l] && (l + 1 >= layers || !st->hdrop[l])) return -1;
+  }
+  if (!st->hout[layers - 1]) return -1;
+  if (layers == 2)
+    hipLaunchKernelGGL(s2g_k_lstm64_stack_fwd<2>, dim3(nseq), dim3(X_G * 2), 0, ST(stream), *st, lengths, T);
+  else
+    hipLaunchKernelGGL(s2g_k_lstm64_stack_fwd<3>, dim3(nseq), dim3(X_G * 3), 0, ST(stream), *st, lengths, T);
+  return LAUNCH_OK();
+}
 int s2g_lstm64_bwd(const float* dh_in, const float* whh, const int* lengths, int nseq, int T, const float* gates,
                    const float* cst, float* delta, void* stream) {
   if (!dh_in || !whh || !gates || !cst || !delta || nseq <= 0 || T <= 0) return -1;

@@ -5,13 +5,14 @@ kernel; one LSTM layer = one batched input product + one sweep over time; weight
 products over the saved gate gradients."""
 from __future__ import annotations
 
+import ctypes
 from typing import Dict, List, Optional
 
 import torch
 
 from . import ops
 from .critic import FlatBuffer
-from .lib import S2GError, call, get
+from .lib import S2GError, S2GLstm64Stack, call, get
 from .ops import ptr, stream_ptr
 
 HID, G4X, EMB = 64, 256, 32
@@ -65,6 +66,8 @@ class _LstmStack:
     def forward(self, x: torch.Tensor, B: int, T: int, lengths: Optional[torch.Tensor],
                 masks: Optional[List[Optional[torch.Tensor]]], save: bool):
         p, dev, rows = self.p.views, self.device, B * T
+        if self.layers in (2, 3):
+            return self._forward_fused(x, B, T, lengths, masks, save)
         inp, saved = x, []
         for l in range(self.layers):
             # b_ih + b_hh (adjacent views of the flat buffer) -> one bias for the batched input product
@@ -80,6 +83,34 @@ class _LstmStack:
             if save:
                 saved.append(dict(inp=inp, gates=gates, cst=cst, hout=hout, mask=mask))
             inp = hdrop if hdrop is not None else hout
+        return hout, saved
+
+    def _forward_fused(self, x: torch.Tensor, B: int, T: int, lengths: Optional[torch.Tensor],
+                       masks: Optional[List[Optional[torch.Tensor]]], save: bool):
+        """All layers in one sweep (s2g_lstm64_stack_fwd): only layer 0 takes a batched input product."""
+        p, dev, rows, NL = self.p.views, self.device, B * T, self.layers
+        for l in range(NL):
+            ops.reduce_slabs(p[f"lstm.bias_ih_l{l}"], G4X, 2, 1, G4X, self.bsum[l])
+        pin = torch.empty(rows, G4X, device=dev)
+        ops.linear_fwd(x, p["lstm.weight_ih_l0"], self.bsum[0], pin)
+        st, saved, inp = S2GLstm64Stack(), [], x
+        st.pin0 = ptr(pin)
+        for l in range(NL):
+            top = l + 1 == NL
+            mask = masks[l] if (masks is not None and not top) else None
+            gates = torch.empty(rows, G4X, device=dev) if save else None
+            cst = torch.empty(rows, HID, device=dev) if save else None
+            hout = torch.empty(rows, HID, device=dev) if (save or top) else None
+            hdrop = torch.empty(rows, HID, device=dev) if mask is not None else None
+            st.whh[l] = ptr(p[f"lstm.weight_hh_l{l}"])
+            if l:
+                st.wih[l], st.bsum[l] = ptr(p[f"lstm.weight_ih_l{l}"]), ptr(self.bsum[l])
+            st.gates[l], st.cst[l], st.hout[l], st.mask[l], st.hdrop[l] = (ptr(gates), ptr(cst), ptr(hout), ptr(mask),
+                                                                          ptr(hdrop))
+            if save:
+                saved.append(dict(inp=inp, gates=gates, cst=cst, hout=hout, mask=mask))
+            inp = hdrop if hdrop is not None else hout
+        call("s2g_lstm64_stack_fwd", ctypes.byref(st), NL, ptr(lengths), B, T, stream_ptr())
         return hout, saved
 
     def backward(self, dh: torch.Tensor, saved, B: int, T: int, lengths: Optional[torch.Tensor], g: Dict[str, torch.Tensor],
