@@ -363,6 +363,19 @@ int s2g_lstm64_stack_fwd(const S2GLstm64Stack* st, int layers, const int* length
  * the gate pre-activations (zeros beyond the length); weight / input gradients are batched products of delta. */
 int s2g_lstm64_bwd(const float* dh_in, const float* whh, const int* lengths, int nseq, int T, const float* gates,
                    const float* cst, float* delta, void* stream);
+/* the autograd of a TWO-layer stack in one reverse sweep (Discriminator's nn.LSTM(64, 64, 2, dropout), wgan.py:100):
+ * dh_top [rows, 64] reaches the top layer's h; the gradient reaching layer 0's h, mask0 * (delta1 W_ih1), stays on
+ * chip; delta[l] [rows, 256] as s2g_lstm64_bwd writes them.  mask0 NULL = no dropout between the layers. */
+typedef struct S2GLstm64StackBwd {
+  const float* dh_top;
+  const float* whh[2];
+  const float* wih1;
+  const float* gates[2];
+  const float* cst[2];
+  const float* mask0;
+  float* delta[2];
+} S2GLstm64StackBwd;
+int s2g_lstm64_stack_bwd(const S2GLstm64StackBwd* st, const int* lengths, int nseq, int T, void* stream);
 /* x [rows, 64] = (emb[token] | lab_emb[label of the sequence]): label_embedding / RelaxedEmbedding lookup + concat
  * (wgan.py:39-42, 107-111); soft != 0: columns 0..31 already hold y @ emb (the matmul branch, :45). */
 int s2g_embed_concat(const int* tokens, const float* emb, int V, const long long* labels, const float* lab_emb,

@@ -343,6 +343,156 @@ extern "C" __global__ __launch_bounds__(X_G) void s2g_k_lstm64_bwd(const float* 
   for (size_t e = (size_t)len * X_G + tid; e < (size_t)T * X_G; e += X_G) delta[r0 * X_G + e] = 0.0f;
 }
 
+// Reverse sweep of a two-layer stack in one launch: group 0 (256 threads) runs the top layer at step len - 1 - s at
+// tick s, group 1 the layer below one tick behind; the gradient reaching the lower layer's h_t,
+// mask_t * (W_ih1^T delta1_t), never leaves the chip (no batched dX product, no multiply by the mask afterwards).
+// Thread (row R of 16 lanes, lane m): partial sums of outputs 4R..4R+3 over gate rows [16 m, 16 m + 16) -- four
+// 16-byte LDS reads per product -- then a transpose-reduce over the 16 lanes (quad exchange + two row rotations)
+// leaves lane m with the sum for unit 4R + (m & 3), and the lane computes the gradient of gate m >> 2 of that
+// unit: all 256 lanes share the cell section, and a tick has one barrier (the gate gradients are double buffered).
+struct S2GLstm64StackBwd {   // mirrors include/s2g.h
+  const float* dh_top;       // [rows, 64] gradient reaching the top layer's h
+  const float* whh[2];       // [256, 64], layer 0 and 1
+  const float* wih1;         // [256, 64] W_ih of layer 1
+  const float* gates[2];     // saved by the forward sweep
+  const float* cst[2];
+  const float* mask0;        // [rows, 64] dropout multiplier between the layers (optional)
+  float* delta[2];           // [rows, 256] gradients of the gate pre-activations (zeros beyond the length)
+};
+
+// sum over the 16 lanes of a DPP row of their partial sums p0..p3 of four outputs: lane m gets output m & 3
+__device__ __forceinline__ float row16_out_sum(f2 pa, f2 pb, int m) {
+  float v = quad_gate_sum(pa.x, pa.y, pb.x, pb.y, m & 3);
+  v += dpp_mov<DPP_ROW_ROR(4)>(v);
+  v += dpp_mov<DPP_ROW_ROR(8)>(v);
+  return v;
+}
+// (pa, pb) += W^T slice (as output pairs 0|1 and 2|3) times the 16 gate gradients of this lane's slice
+__device__ __forceinline__ void x_slice_fma_t(const f2 (&w01)[16], const f2 (&w23)[16], const float* slice, f2& pa,
+                                              f2& pb) {
+  const f4* v4 = reinterpret_cast<const f4*>(slice);
+  f2 qa = {0.0f, 0.0f}, qb = {0.0f, 0.0f};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const f4 v = v4[k];
+    pa = __builtin_elementwise_fma(w01[4 * k], (f2){v.x, v.x}, pa);
+    pb = __builtin_elementwise_fma(w23[4 * k], (f2){v.x, v.x}, pb);
+    qa = __builtin_elementwise_fma(w01[4 * k + 1], (f2){v.y, v.y}, qa);
+    qb = __builtin_elementwise_fma(w23[4 * k + 1], (f2){v.y, v.y}, qb);
+    pa = __builtin_elementwise_fma(w01[4 * k + 2], (f2){v.z, v.z}, pa);
+    pb = __builtin_elementwise_fma(w23[4 * k + 2], (f2){v.z, v.z}, pb);
+    qa = __builtin_elementwise_fma(w01[4 * k + 3], (f2){v.w, v.w}, qa);
+    qb = __builtin_elementwise_fma(w23[4 * k + 3], (f2){v.w, v.w}, qb);
+  }
+  pa += qa;
+  pb += qb;
+}
+
+extern "C" __global__ __launch_bounds__(2 * X_G) void s2g_k_lstm64_stack_bwd(S2GLstm64StackBwd a,
+                                                                             const int* __restrict__ lengths, int T) {
+  __shared__ __attribute__((aligned(16))) float ds[2][2][X_G];     // [group][buffer][gate row]
+  const int n = blockIdx.x;
+  const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8), j = threadIdx.x & (X_G - 1);
+  const int R = j >> 4, m = j & 15;
+  const int u = 4 * R + (m & 3), gate = m >> 2;
+  const int len = lengths ? min(max(lengths[n], 0), T) : T;
+  const int nticks = len > 0 ? ((len + 1 + X_PF - 1) / X_PF) * X_PF : 0;
+  const int lastrow = max(len - 1, 0);
+  const size_t r0 = (size_t)n * T;
+  for (int e = threadIdx.x; e < 2 * 2 * X_G; e += 2 * X_G) (&ds[0][0][0])[e] = 0.0f;
+  const int layer = 1 - grp;
+  const float* __restrict__ gates = a.gates[layer];
+  const float* __restrict__ cst = a.cst[layer];
+  float* __restrict__ delta = a.delta[layer];
+  const float* whh = a.whh[layer];
+  // own recurrent weights: W_hh[16 m + rr][4R + o]
+  f2 w01[16], w23[16];
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) {
+    w01[rr] = *reinterpret_cast<const f2*>(whh + (16 * m + rr) * X_H + 4 * R);
+    w23[rr] = *reinterpret_cast<const f2*>(whh + (16 * m + rr) * X_H + 4 * R + 2);
+  }
+  float dc = 0.0f;
+  float n_x[X_PF], n_gi[X_PF], n_gf[X_PF], n_gg[X_PF], n_go[X_PF], n_c[X_PF], n_cp[X_PF];
+  if (grp == 0) {
+    const float* __restrict__ dh_in = a.dh_top;
+#define XB_FETCH(i, t_)                                                       \
+  {                                                                           \
+    const size_t r = r0 + min(max((t_), 0), lastrow);                         \
+    n_x[i] = px[r * sx];                                                      \
+    n_gi[i] = gates[r * X_G + u]; n_gf[i] = gates[r * X_G + X_H + u];         \
+    n_gg[i] = gates[r * X_G + 2 * X_H + u]; n_go[i] = gates[r * X_G + 3 * X_H + u]; \
+    n_c[i] = cst[r * X_H + u];                                                \
+    n_cp[i] = cst[(r0 + min(max((t_) - 1, 0), lastrow)) * X_H + u];           \
+  }
+#define XB_CELL(dh_)                                                          \
+  const float gi = n_gi[i], gf = n_gf[i], gg = n_gg[i], go = n_go[i];         \
+  const float cprev = t > 0 ? n_cp[i] : 0.0f;                                 \
+  const float tc = fast_tanh(n_c[i]);                                         \
+  const float dh = (dh_);                                                     \
+  const float dct = fmaf(dh * go, 1.0f - tc * tc, dc);                        \
+  const float di = dct * gg * gi * (1.0f - gi);                               \
+  const float df = dct * cprev * gf * (1.0f - gf);                            \
+  const float dg = dct * gi * (1.0f - gg * gg);                               \
+  const float dO = dh * tc * go * (1.0f - go);                                \
+  dc = live ? dct * gf : dc;                                                  \
+  const float mine0 = gate == 0 ? di : gate == 1 ? df : gate == 2 ? dg : dO;  \
+  const float mine = live ? mine0 : 0.0f;                                     \
+  ds[grp][(tick + 1) & 1][gate * X_H + u] = mine;                             \
+  if (live) delta[(r0 + t) * X_G + gate * X_H + u] = mine;
+    const float* px = dh_in + u;
+    const size_t sx = X_H;
+#pragma unroll
+    for (int i = 0; i < X_PF; ++i) XB_FETCH(i, len - 1 - i)
+    __syncthreads();
+    for (int base = 0; base < nticks; base += X_PF) {
+#pragma unroll
+      for (int i = 0; i < X_PF; ++i) {
+        const int tick = base + i, t = len - 1 - tick;
+        const bool live = t >= 0;
+        f2 pa = {0.0f, 0.0f}, pb = {0.0f, 0.0f};
+        x_slice_fma_t(w01, w23, ds[0][tick & 1] + 16 * m, pa, pb);
+        const float rec = row16_out_sum(pa, pb, m);
+        XB_CELL(n_x[i] + rec)
+        XB_FETCH(i, t - X_PF)
+        __syncthreads();
+      }
+    }
+  } else {
+    // W_ih of the layer above, same slicing: the gradient reaching this layer's h from above
+    f2 v01[16], v23[16];
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      v01[rr] = *reinterpret_cast<const f2*>(a.wih1 + (16 * m + rr) * X_H + 4 * R);
+      v23[rr] = *reinterpret_cast<const f2*>(a.wih1 + (16 * m + rr) * X_H + 4 * R + 2);
+    }
+    const bool has_mask = a.mask0 != nullptr;
+    const float* px = has_mask ? a.mask0 + u : whh;        // without a mask: a harmless load, the value is not used
+    const size_t sx = has_mask ? X_H : 0;
+#pragma unroll
+    for (int i = 0; i < X_PF; ++i) XB_FETCH(i, len - i)
+    __syncthreads();
+    for (int base = 0; base < nticks; base += X_PF) {
+#pragma unroll
+      for (int i = 0; i < X_PF; ++i) {
+        const int tick = base + i, t = len - tick;         // one tick behind the layer above
+        const bool live = t >= 0 && t < len;
+        f2 pa = {0.0f, 0.0f}, pb = {0.0f, 0.0f}, xa = {0.0f, 0.0f}, xb = {0.0f, 0.0f};
+        x_slice_fma_t(w01, w23, ds[1][tick & 1] + 16 * m, pa, pb);
+        x_slice_fma_t(v01, v23, ds[0][tick & 1] + 16 * m, xa, xb);
+        const float rec = row16_out_sum(pa, pb, m);
+        const float above = row16_out_sum(xa, xb, m);
+        XB_CELL(fmaf(has_mask ? n_x[i] : 1.0f, above, rec))
+        XB_FETCH(i, t - X_PF)
+        __syncthreads();
+      }
+    }
+  }
+#undef XB_FETCH
+#undef XB_CELL
+  for (size_t e = (size_t)len * X_G + j; e < (size_t)T * X_G; e += X_G) delta[r0 * X_G + e] = 0.0f;
+}
+
 // x[row] = (emb[token[row]] | label_emb[label[n]])  (wgan.py:107-111 with the lookup branch of RelaxedEmbedding,
 // :39-42); token ids clamped to the table.  soft != 0: the first 32 columns already hold y @ emb (the matmul
 // branch, :45) and only the label half is written.

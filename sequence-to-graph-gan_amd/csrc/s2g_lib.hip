@@ -576,6 +576,13 @@ int s2g_lstm64_bwd(const float* dh_in, const float* whh, const int* lengths, int
   hipLaunchKernelGGL(s2g_k_lstm64_bwd, dim3(nseq), dim3(X_G), 0, ST(stream), dh_in, whh, lengths, T, gates, cst, delta);
   return LAUNCH_OK();
 }
+int s2g_lstm64_stack_bwd(const S2GLstm64StackBwd* st, const int* lengths, int nseq, int T, void* stream) {
+  if (!st || nseq <= 0 || T <= 0 || !st->dh_top || !st->wih1) return -1;
+  for (int l = 0; l < 2; ++l)
+    if (!st->whh[l] || !st->gates[l] || !st->cst[l] || !st->delta[l]) return -1;
+  hipLaunchKernelGGL(s2g_k_lstm64_stack_bwd, dim3(nseq), dim3(2 * X_G), 0, ST(stream), *st, lengths, T);
+  return LAUNCH_OK();
+}
 int s2g_embed_concat(const int* tokens, const float* emb, int V, const long long* labels, const float* lab_emb,
                      int n_classes, int T, long rows, int soft, float* x, void* stream) {
   if (!emb || !labels || !lab_emb || !x || V <= 0 || n_classes <= 0 || T <= 0 || rows <= 0) return -1;

@@ -42,6 +42,11 @@ class S2GLstm64Stack(ctypes.Structure):
     _fields_ = [("pin0", P)] + [(k, P * 3) for k in ("whh", "wih", "bsum", "gates", "cst", "hout", "mask", "hdrop")]
 
 
+class S2GLstm64StackBwd(ctypes.Structure):
+    _fields_ = [("dh_top", P), ("whh", P * 2), ("wih1", P), ("gates", P * 2), ("cst", P * 2), ("mask0", P),
+                ("delta", P * 2)]
+
+
 class S2GReduce(ctypes.Structure):
     _fields_ = [("slabs", P), ("slab", L), ("out", P), ("nslab", I), ("rows", I), ("cols", I)]
 
@@ -111,6 +116,7 @@ SIGNATURES = {
     "s2g_lstm64_fwd": [P, P, P, I, I, P, P, P, P, P, P],
     "s2g_lstm64_bwd": [P, P, P, I, I, P, P, P, P],
     "s2g_lstm64_stack_fwd": [ctypes.POINTER(S2GLstm64Stack), I, P, I, I, P],
+    "s2g_lstm64_stack_bwd": [ctypes.POINTER(S2GLstm64StackBwd), P, I, I, P],
     "s2g_embed_concat": [P, P, I, P, P, I, I, L, I, P, P],
     "s2g_embed_grad_tokens_scratch": [L, I],
     "s2g_embed_grad_tokens": [P, P, I, L, I, P, P, I, P, P],

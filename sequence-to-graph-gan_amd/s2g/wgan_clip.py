@@ -12,7 +12,7 @@ import torch
 
 from . import ops
 from .critic import FlatBuffer
-from .lib import S2GError, S2GLstm64Stack, call, get
+from .lib import S2GError, S2GLstm64Stack, S2GLstm64StackBwd, call, get
 from .ops import ptr, stream_ptr
 
 HID, G4X, EMB = 64, 256, 32
@@ -118,15 +118,30 @@ class _LstmStack:
         """dh [rows, 64]: gradient of the top layer's outputs.  Accumulates the LSTM parameter gradients into g
         and returns the gradient of the stack's input [rows, 64]."""
         p, dev, rows = self.p.views, self.device, B * T
+        fused = None
+        if self.layers == 2:
+            # both reverse sweeps in one launch; layer 0's incoming gradient never leaves the chip
+            fused = [torch.empty(rows, G4X, device=dev) for _ in range(2)]
+            st = S2GLstm64StackBwd()
+            st.dh_top, st.wih1, st.mask0 = ptr(dh), ptr(p["lstm.weight_ih_l1"]), ptr(saved[0]["mask"])
+            for l in range(2):
+                st.whh[l], st.gates[l], st.cst[l], st.delta[l] = (ptr(p[f"lstm.weight_hh_l{l}"]), ptr(saved[l]["gates"]),
+                                                                ptr(saved[l]["cst"]), ptr(fused[l]))
+            call("s2g_lstm64_stack_bwd", ctypes.byref(st), ptr(lengths), B, T, stream_ptr())
         for l in reversed(range(self.layers)):
             s = saved[l]
-            delta = torch.empty(rows, G4X, device=dev)
-            call("s2g_lstm64_bwd", ptr(dh), ptr(p[f"lstm.weight_hh_l{l}"]), ptr(lengths), B, T, ptr(s["gates"]),
-                 ptr(s["cst"]), ptr(delta), stream_ptr())
+            if fused is not None:
+                delta = fused[l]
+            else:
+                delta = torch.empty(rows, G4X, device=dev)
+                call("s2g_lstm64_bwd", ptr(dh), ptr(p[f"lstm.weight_hh_l{l}"]), ptr(lengths), B, T, ptr(s["gates"]),
+                     ptr(s["cst"]), ptr(delta), stream_ptr())
             _tn(ptr(delta), G4X, G4X, ptr(s["inp"]), HID, HID, rows, g[f"lstm.weight_ih_l{l}"], scratch, accumulate)
             _tn(ptr(delta), G4X, G4X, ptr(s["hout"]), HID, HID, rows, g[f"lstm.weight_hh_l{l}"], scratch, accumulate,
                 segT=T, shift=True)
             ops.colsum(delta, rows, G4X, G4X, g[f"lstm.bias_ih_l{l}"], scratch, accumulate=accumulate)
+            if fused is not None and l > 0:
+                continue                  # the sweep below already took delta W_ih (times the mask) on chip
             dinp = torch.empty(rows, HID, device=dev)
             ops.linear_bwd_dx(delta, p[f"lstm.weight_ih_l{l}"], dinp, scratch)
             if l > 0 and saved[l - 1]["mask"] is not None:
