@@ -56,6 +56,24 @@ def _tn(A: int, lda: int, M: int, B: int, ldb: int, N: int, K: int, out: torch.T
         ops.reduce_slabs(slabs, M * N, ns, M, N, out, accumulate=accumulate)
 
 
+class _Fan:
+    """Two more streams, each with split-K scratch of its own, for the weight-gradient products of a long pass
+    that nothing later in the pass waits for: they leave its critical chain of sweeps."""
+
+    def __init__(self, stream_b: torch.cuda.Stream, scratch_b: ops.Scratch, device):
+        self.b, self.scratch_b = stream_b, scratch_b
+        self.c, self.scratch_c = torch.cuda.Stream(device=device), ops.Scratch(device)
+        self.fork_ev = [torch.cuda.Event() for _ in range(2)]
+        self.join_ev = [torch.cuda.Event() for _ in range(2)]
+
+    def join(self) -> None:
+        """The current stream waits for everything queued on the two streams so far."""
+        cur = torch.cuda.current_stream()
+        for stream, ev in zip((self.b, self.c), self.join_ev):
+            ev.record(stream)
+            cur.wait_event(ev)
+
+
 class _LstmStack:
     """Shared by both networks: the layers of an nn.LSTM(64, 64, layers, batch_first=True)."""
 
@@ -114,10 +132,19 @@ class _LstmStack:
         return hout, saved
 
     def backward(self, dh: torch.Tensor, saved, B: int, T: int, lengths: Optional[torch.Tensor], g: Dict[str, torch.Tensor],
-                 scratch: ops.Scratch, accumulate: bool) -> torch.Tensor:
+                 scratch: ops.Scratch, accumulate: bool, fan: Optional[_Fan] = None) -> torch.Tensor:
         """dh [rows, 64]: gradient of the top layer's outputs.  Accumulates the LSTM parameter gradients into g
-        and returns the gradient of the stack's input [rows, 64]."""
+        and returns the gradient of the stack's input [rows, 64].  fan (two-layer stacks): the weight-gradient
+        products run on its streams, layer 1's on one and layer 0's on the other; the caller joins them."""
         p, dev, rows = self.p.views, self.device, B * T
+
+        def weight_grads(l, delta, sc):
+            s = saved[l]
+            _tn(ptr(delta), G4X, G4X, ptr(s["inp"]), HID, HID, rows, g[f"lstm.weight_ih_l{l}"], sc, accumulate)
+            _tn(ptr(delta), G4X, G4X, ptr(s["hout"]), HID, HID, rows, g[f"lstm.weight_hh_l{l}"], sc, accumulate,
+                segT=T, shift=True)
+            ops.colsum(delta, rows, G4X, G4X, g[f"lstm.bias_ih_l{l}"], sc, accumulate=accumulate)
+
         fused = None
         if self.layers == 2:
             # both reverse sweeps in one launch; layer 0's incoming gradient never leaves the chip
@@ -128,6 +155,15 @@ class _LstmStack:
                 st.whh[l], st.gates[l], st.cst[l], st.delta[l] = (ptr(p[f"lstm.weight_hh_l{l}"]), ptr(saved[l]["gates"]),
                                                                 ptr(saved[l]["cst"]), ptr(fused[l]))
             call("s2g_lstm64_stack_bwd", ctypes.byref(st), ptr(lengths), B, T, stream_ptr())
+            if fan is not None:
+                fan.fork_ev[1].record()
+                for l, stream, sc in ((1, fan.b, fan.scratch_b), (0, fan.c, fan.scratch_c)):
+                    with ops.on_stream(stream):
+                        stream.wait_event(fan.fork_ev[1])
+                        weight_grads(l, fused[l], sc)
+                dinp = torch.empty(rows, HID, device=dev)
+                ops.linear_bwd_dx(fused[0], p["lstm.weight_ih_l0"], dinp, scratch)
+                return dinp
         for l in reversed(range(self.layers)):
             s = saved[l]
             if fused is not None:
@@ -136,10 +172,7 @@ class _LstmStack:
                 delta = torch.empty(rows, G4X, device=dev)
                 call("s2g_lstm64_bwd", ptr(dh), ptr(p[f"lstm.weight_hh_l{l}"]), ptr(lengths), B, T, ptr(s["gates"]),
                      ptr(s["cst"]), ptr(delta), stream_ptr())
-            _tn(ptr(delta), G4X, G4X, ptr(s["inp"]), HID, HID, rows, g[f"lstm.weight_ih_l{l}"], scratch, accumulate)
-            _tn(ptr(delta), G4X, G4X, ptr(s["hout"]), HID, HID, rows, g[f"lstm.weight_hh_l{l}"], scratch, accumulate,
-                segT=T, shift=True)
-            ops.colsum(delta, rows, G4X, G4X, g[f"lstm.bias_ih_l{l}"], scratch, accumulate=accumulate)
+            weight_grads(l, delta, scratch)
             if fused is not None and l > 0:
                 continue                  # the sweep below already took delta W_ih (times the mask) on chip
             dinp = torch.empty(rows, HID, device=dev)
@@ -230,9 +263,11 @@ class ClipCriticEngine:
                      weights=weights, pooled=pooled, lstm=saved) if save else None
         return dval, state
 
-    def backward(self, st, dD: torch.Tensor, accumulate: bool, grads=None, scratch=None) -> None:
+    def backward(self, st, dD: torch.Tensor, accumulate: bool, grads=None, scratch=None,
+                 fan: Optional[_Fan] = None) -> None:
         """Adds (or writes, accumulate=False) the parameter gradients of sum_n dD[n] * D_n into self.grads
-        (or `grads`, with `scratch` for the split-K slabs: a pass that runs beside another needs both of its own)."""
+        (or `grads`, with `scratch` for the split-K slabs: a pass that runs beside another needs both of its own).
+        fan: streams for the weight-gradient products off the chain of sweeps; joined before this returns."""
         p, g, dev, sc = self.params.views, (grads or self.grads).views, self.device, scratch or self.scratch
         B, T, Tp, rows = st["B"], st["T"], st["Tp"], st["B"] * st["T"]
         dout = torch.empty(rows, HID, device=dev)
@@ -240,15 +275,26 @@ class ClipCriticEngine:
         call("s2g_attnpool_bwd", ptr(st["a"]), ptr(st["out"]), ptr(p["attention.context_vector.weight"]),
              ptr(p["linear.weight"]), ptr(st["weights"]), ptr(dD), B, T, Tp, ptr(dout), ptr(dwc), stream_ptr())
         dpre = st["a"]
-        ops.colsum(dwc, B, HID, HID, g["attention.context_vector.weight"], sc, accumulate=accumulate)
-        _tn(ptr(dD), 1, 1, ptr(st["pooled"]), HID, HID, B, g["linear.weight"], sc, accumulate)
-        ops.colsum(dD, B, 1, 1, g["linear.bias"], sc, accumulate=accumulate)
-        _tn(ptr(dpre), HID, HID, ptr(st["out"]), HID, HID, rows, g["attention.attn.weight"], sc, accumulate)
-        ops.colsum(dpre, rows, HID, HID, g["attention.attn.bias"], sc, accumulate=accumulate)
+
+        def head_grads(sc_):
+            ops.colsum(dwc, B, HID, HID, g["attention.context_vector.weight"], sc_, accumulate=accumulate)
+            _tn(ptr(dD), 1, 1, ptr(st["pooled"]), HID, HID, B, g["linear.weight"], sc_, accumulate)
+            ops.colsum(dD, B, 1, 1, g["linear.bias"], sc_, accumulate=accumulate)
+            _tn(ptr(dpre), HID, HID, ptr(st["out"]), HID, HID, rows, g["attention.attn.weight"], sc_, accumulate)
+            ops.colsum(dpre, rows, HID, HID, g["attention.attn.bias"], sc_, accumulate=accumulate)
+
+        if fan is not None and self.layers == 2:
+            fan.fork_ev[0].record()
+            with ops.on_stream(fan.b):
+                fan.b.wait_event(fan.fork_ev[0])
+                head_grads(fan.scratch_b)
+        else:
+            fan = None
+            head_grads(sc)
         # d(out) += d(pre) Wa
         ops.gemm_raw(ptr(dpre), HID, 1, ptr(p["attention.attn.weight"]), HID, 1, ptr(dout), HID, rows, HID, HID,
                      accumulate=True)
-        dx = self.stack.backward(dout, st["lstm"], B, T, st["lengths"], g, sc, accumulate)
+        dx = self.stack.backward(dout, st["lstm"], B, T, st["lengths"], g, sc, accumulate, fan)
         ge = g["sequence_embedding.embed_layer.weight"]
         if st["soft"]:
             _tn(ptr(st["seq"]), self.V, self.V, ptr(dx), 2 * EMB, EMB, rows, ge, sc, accumulate)
@@ -262,6 +308,8 @@ class ClipCriticEngine:
         part = sc.get(B * 32)
         call("s2g_embed_grad_labels", ptr(st["labels"]), ptr(st["lengths"]), T, B, self.n_classes, ptr(dx),
              ptr(g["label_embedding.weight"]), int(accumulate), ptr(part), stream_ptr())
+        if fan is not None:
+            fan.join()
 
     def dropout_masks(self, rows: int):
         if self.dropout <= 0.0:
@@ -301,6 +349,7 @@ class ClipCriticEngine:
             if self._side is None:
                 self._side = (torch.cuda.Stream(device=dev), self.params.like(), ops.Scratch(dev),
                               [torch.cuda.Event() for _ in range(4)])
+                self._fan = _Fan(self._side[0], self._side[2], dev)
             side, grads2, scratch2, (e_in, e_fwd, e_loss, e_bwd) = self._side
             cur = torch.cuda.current_stream()
             e_in.record()
@@ -318,7 +367,8 @@ class ClipCriticEngine:
                 side.wait_event(e_loss)
                 self.backward(s_fake, dD[B:], accumulate=False, grads=grads2, scratch=scratch2)
                 e_bwd.record()
-            self.backward(s_real, dD[:B], accumulate=False)
+            # the real pass's weight-gradient products follow the (short) fake pass on the second stream and on a third
+            self.backward(s_real, dD[:B], accumulate=False, fan=self._fan)
             cur.wait_event(e_bwd)
             call("s2g_add_inplace", ptr(self.grads.flat), ptr(grads2.flat), self.grads.total, stream_ptr())
         else:
