@@ -368,13 +368,17 @@ __device__ __forceinline__ float row16_out_sum(f2 pa, f2 pb, int m) {
   return v;
 }
 // (pa, pb) += W^T slice (as output pairs 0|1 and 2|3) times the 16 gate gradients of this lane's slice
-__device__ __forceinline__ void x_slice_fma_t(const f2 (&w01)[16], const f2 (&w23)[16], const float* slice, f2& pa,
+// The vector is stored so that the k-th 16-byte piece of lane m's slice sits at piece 16 k + m: the 16 lanes of a
+// row then read 256 consecutive bytes (pieces 64 bytes apart would put lanes m, m + 4, m + 8, m + 12 on the same
+// banks: a four-way conflict on every read).
+__device__ __forceinline__ int x_tpos(int e) { return ((((e >> 2) & 3) * 16 + (e >> 4)) << 2) + (e & 3); }
+__device__ __forceinline__ void x_slice_fma_t(const f2 (&w01)[16], const f2 (&w23)[16], const float* vec, int m, f2& pa,
                                               f2& pb) {
-  const f4* v4 = reinterpret_cast<const f4*>(slice);
+  const f4* v4 = reinterpret_cast<const f4*>(vec) + m;
   f2 qa = {0.0f, 0.0f}, qb = {0.0f, 0.0f};
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const f4 v = v4[k];
+    const f4 v = v4[16 * k];
     pa = __builtin_elementwise_fma(w01[4 * k], (f2){v.x, v.x}, pa);
     pb = __builtin_elementwise_fma(w23[4 * k], (f2){v.x, v.x}, pb);
     qa = __builtin_elementwise_fma(w01[4 * k + 1], (f2){v.y, v.y}, qa);
@@ -395,6 +399,7 @@ extern "C" __global__ __launch_bounds__(2 * X_G) void s2g_k_lstm64_stack_bwd(S2G
   const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8), j = threadIdx.x & (X_G - 1);
   const int R = j >> 4, m = j & 15;
   const int u = 4 * R + (m & 3), gate = m >> 2;
+  const int wpos = x_tpos(gate * X_H + u);
   const int len = lengths ? min(max(lengths[n], 0), T) : T;
   const int nticks = len > 0 ? ((len + 1 + X_PF - 1) / X_PF) * X_PF : 0;
   const int lastrow = max(len - 1, 0);
@@ -438,7 +443,7 @@ extern "C" __global__ __launch_bounds__(2 * X_G) void s2g_k_lstm64_stack_bwd(S2G
   dc = live ? dct * gf : dc;                                                  \
   const float mine0 = gate == 0 ? di : gate == 1 ? df : gate == 2 ? dg : dO;  \
   const float mine = live ? mine0 : 0.0f;                                     \
-  ds[grp][(tick + 1) & 1][gate * X_H + u] = mine;                             \
+  ds[grp][(tick + 1) & 1][wpos] = mine;                                       \
   if (live) delta[(r0 + t) * X_G + gate * X_H + u] = mine;
     const float* px = dh_in + u;
     const size_t sx = X_H;
@@ -451,7 +456,7 @@ extern "C" __global__ __launch_bounds__(2 * X_G) void s2g_k_lstm64_stack_bwd(S2G
         const int tick = base + i, t = len - 1 - tick;
         const bool live = t >= 0;
         f2 pa = {0.0f, 0.0f}, pb = {0.0f, 0.0f};
-        x_slice_fma_t(w01, w23, ds[0][tick & 1] + 16 * m, pa, pb);
+        x_slice_fma_t(w01, w23, ds[0][tick & 1], m, pa, pb);
         const float rec = row16_out_sum(pa, pb, m);
         XB_CELL(n_x[i] + rec)
         XB_FETCH(i, t - X_PF)
@@ -478,8 +483,8 @@ extern "C" __global__ __launch_bounds__(2 * X_G) void s2g_k_lstm64_stack_bwd(S2G
         const int tick = base + i, t = len - tick;         // one tick behind the layer above
         const bool live = t >= 0 && t < len;
         f2 pa = {0.0f, 0.0f}, pb = {0.0f, 0.0f}, xa = {0.0f, 0.0f}, xb = {0.0f, 0.0f};
-        x_slice_fma_t(w01, w23, ds[1][tick & 1] + 16 * m, pa, pb);
-        x_slice_fma_t(v01, v23, ds[0][tick & 1] + 16 * m, xa, xb);
+        x_slice_fma_t(w01, w23, ds[1][tick & 1], m, pa, pb);
+        x_slice_fma_t(v01, v23, ds[0][tick & 1], m, xa, xb);
         const float rec = row16_out_sum(pa, pb, m);
         const float above = row16_out_sum(xa, xb, m);
         XB_CELL(fmaf(has_mask ? n_x[i] : 1.0f, above, rec))
