@@ -606,27 +606,28 @@ extern "C" __global__ __launch_bounds__(32) void s2g_k_embed_grad_labels(const l
 // weights = softmax over ALL Tp positions (padded rows hold out = 0, so their score is wc . tanh(ba): they
 // take part in the softmax, as in the reference); pooled = sum_t weights_t out_t; D = wl . pooled + bl.
 // One workgroup per sequence.  Saves tanh(pre) in place, the weights and pooled for the backward pass.
-extern "C" __global__ __launch_bounds__(256) void s2g_k_attnpool_fwd(float* __restrict__ pre, const float* __restrict__ out,
+#define AP_NW 16        // waves per workgroup: the row loops are latency bound, so a sequence gets a whole CU's worth
+extern "C" __global__ __launch_bounds__(64 * AP_NW) void s2g_k_attnpool_fwd(float* __restrict__ pre, const float* __restrict__ out,
                                                                      const float* __restrict__ wc,
                                                                      const float* __restrict__ wl,
                                                                      const float* __restrict__ bl, int T, int Tp,
                                                                      float* __restrict__ weights,
                                                                      float* __restrict__ pooled, float* __restrict__ dval) {
   extern __shared__ float sc[];             // [Tp] scores, then weights
-  __shared__ float red[4][X_H];
+  __shared__ float red[AP_NW][X_H];
   __shared__ float stat[2];
   const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const size_t r0 = (size_t)n * T;
   const float wk = wc[lane];
   // (the row loops are unrolled eight deep so that eight rows' loads are in flight together: one row at a time,
   // every iteration paid a memory round trip)
-  for (int tb = wave; tb < Tp; tb += 32) {
+  for (int tb = wave; tb < Tp; tb += 8 * AP_NW) {
     float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = pre[(r0 + min(tb + 4 * j, Tp - 1)) * X_H + lane];
+    for (int j = 0; j < 8; ++j) v[j] = pre[(r0 + min(tb + AP_NW * j, Tp - 1)) * X_H + lane];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int t = tb + 4 * j;
+      const int t = tb + AP_NW * j;
       if (t < Tp) {
         const float a = tanhf(v[j]);
         pre[(r0 + t) * X_H + lane] = a;
@@ -652,7 +653,7 @@ extern "C" __global__ __launch_bounds__(256) void s2g_k_attnpool_fwd(float* __re
   __syncthreads();
   float acc = 0.0f;
 #pragma unroll 8
-  for (int t = wave; t < Tp; t += 4) {
+  for (int t = wave; t < Tp; t += AP_NW) {
     const float wgt = expf(sc[t] - stat[0]) * stat[1];
     if (lane == 0) weights[(size_t)n * T + t] = wgt;
     acc = fmaf(wgt, out[(r0 + t) * X_H + lane], acc);
@@ -660,7 +661,9 @@ extern "C" __global__ __launch_bounds__(256) void s2g_k_attnpool_fwd(float* __re
   red[wave][lane] = acc;
   __syncthreads();
   if (wave == 0) {
-    const float p = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    float p = 0.0f;
+#pragma unroll
+    for (int w = 0; w < AP_NW; ++w) p += red[w][lane];
     pooled[(size_t)n * X_H + lane] = p;
     float s = wl[lane] * p;
 #pragma unroll
@@ -671,25 +674,25 @@ extern "C" __global__ __launch_bounds__(256) void s2g_k_attnpool_fwd(float* __re
 
 // backward of the pooling for d(loss)/d(D_n) = dD[n]: d(out) (direct part: weights_t * dpooled), dpre =
 // ds_t * wc * (1 - a^2) written over a, and this sequence's share of d(wc); d(wl), d(bl) follow from pooled.
-extern "C" __global__ __launch_bounds__(256) void s2g_k_attnpool_bwd(float* __restrict__ a_dpre, const float* __restrict__ out,
+extern "C" __global__ __launch_bounds__(64 * AP_NW) void s2g_k_attnpool_bwd(float* __restrict__ a_dpre, const float* __restrict__ out,
                                                                      const float* __restrict__ wc,
                                                                      const float* __restrict__ wl,
                                                                      const float* __restrict__ weights,
                                                                      const float* __restrict__ dD, int T, int Tp,
                                                                      float* __restrict__ dout, float* __restrict__ dwc_part) {
   extern __shared__ float dw[];             // [Tp] d(weights), then d(scores)
-  __shared__ float red[4][X_H];
+  __shared__ float red[AP_NW][X_H];
   __shared__ float dot_s;
   const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const size_t r0 = (size_t)n * T;
   const float dp = dD[n] * wl[lane];                       // d(pooled)
-  for (int tb = wave; tb < Tp; tb += 32) {
+  for (int tb = wave; tb < Tp; tb += 8 * AP_NW) {
     float ov[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) ov[j] = out[(r0 + min(tb + 4 * j, Tp - 1)) * X_H + lane];
+    for (int j = 0; j < 8; ++j) ov[j] = out[(r0 + min(tb + AP_NW * j, Tp - 1)) * X_H + lane];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int t = tb + 4 * j;
+      const int t = tb + AP_NW * j;
       if (t < Tp) {
         float s = dp * ov[j];
 #pragma unroll
@@ -709,17 +712,17 @@ extern "C" __global__ __launch_bounds__(256) void s2g_k_attnpool_bwd(float* __re
   __syncthreads();
   const float wk = wc[lane];
   float acc = 0.0f;
-  for (int tb = wave; tb < Tp; tb += 32) {
+  for (int tb = wave; tb < Tp; tb += 8 * AP_NW) {
     float av[8], wv[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int tc = min(tb + 4 * j, Tp - 1);
+      const int tc = min(tb + AP_NW * j, Tp - 1);
       av[j] = a_dpre[(r0 + tc) * X_H + lane];
       wv[j] = weights[(size_t)n * T + tc];
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int t = tb + 4 * j;
+      const int t = tb + AP_NW * j;
       if (t < Tp) {
         const float dsc = wv[j] * (dw[t] - dot_s);             // softmax backward
         acc = fmaf(dsc, av[j], acc);                           // d(wc)
@@ -728,13 +731,18 @@ extern "C" __global__ __launch_bounds__(256) void s2g_k_attnpool_bwd(float* __re
       }
     }
   }
-  for (int t = Tp + wave; t < T; t += 4) {                 // rows the pooling never saw
+  for (int t = Tp + wave; t < T; t += AP_NW) {                 // rows the pooling never saw
     a_dpre[(r0 + t) * X_H + lane] = 0.0f;
     dout[(r0 + t) * X_H + lane] = 0.0f;
   }
   red[wave][lane] = acc;
   __syncthreads();
-  if (wave == 0) dwc_part[(size_t)n * X_H + lane] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  if (wave == 0) {
+    float p = 0.0f;
+#pragma unroll
+    for (int w = 0; w < AP_NW; ++w) p += red[w][lane];
+    dwc_part[(size_t)n * X_H + lane] = p;
+  }
 }
 
 // critic loss of the weight-clipping WGAN (wgan.py:145-147, 189): values = [real B | fake B];

@@ -626,7 +626,7 @@ int s2g_attnpool_fwd(float* pre, const float* out, const float* wc, const float*
   if (!pre || !out || !wc || !wl || !bl || !weights || !pooled || !dval || nseq <= 0 || T <= 0 || Tp <= 0 || Tp > T ||
       Tp > 12288)
     return -1;
-  hipLaunchKernelGGL(s2g_k_attnpool_fwd, dim3(nseq), dim3(256), (size_t)Tp * sizeof(float), ST(stream), pre, out, wc, wl,
+  hipLaunchKernelGGL(s2g_k_attnpool_fwd, dim3(nseq), dim3(64 * AP_NW), (size_t)Tp * sizeof(float), ST(stream), pre, out, wc, wl,
                      bl, T, Tp, weights, pooled, dval);
   return LAUNCH_OK();
 }
@@ -635,7 +635,7 @@ int s2g_attnpool_bwd(float* a_dpre, const float* out, const float* wc, const flo
   if (!a_dpre || !out || !wc || !wl || !weights || !dD || !dout || !dwc_part || nseq <= 0 || T <= 0 || Tp <= 0 ||
       Tp > T || Tp > 12288)
     return -1;
-  hipLaunchKernelGGL(s2g_k_attnpool_bwd, dim3(nseq), dim3(256), (size_t)Tp * sizeof(float), ST(stream), a_dpre, out, wc,
+  hipLaunchKernelGGL(s2g_k_attnpool_bwd, dim3(nseq), dim3(64 * AP_NW), (size_t)Tp * sizeof(float), ST(stream), a_dpre, out, wc,
                      wl, weights, dD, T, Tp, dout, dwc_part);
   return LAUNCH_OK();
 }
