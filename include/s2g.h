@@ -374,6 +374,7 @@ typedef struct S2GLstm64StackBwd {
   const float* cst[2];
   const float* mask0;
   float* delta[2];
+  float* bias_part[2];   /* optional [nseq, 256]: per-sequence sums of delta over time (sum them for db) */
 } S2GLstm64StackBwd;
 int s2g_lstm64_stack_bwd(const S2GLstm64StackBwd* st, const int* lengths, int nseq, int T, void* stream);
 /* x [rows, 64] = (emb[token] | lab_emb[label of the sequence]): label_embedding / RelaxedEmbedding lookup + concat

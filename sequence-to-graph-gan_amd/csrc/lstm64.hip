@@ -358,6 +358,7 @@ struct S2GLstm64StackBwd {   // mirrors include/s2g.h
   const float* cst[2];
   const float* mask0;        // [rows, 64] dropout multiplier between the layers (optional)
   float* delta[2];           // [rows, 256] gradients of the gate pre-activations (zeros beyond the length)
+  float* bias_part[2];       // [sequences, 256] per-sequence sums of delta over time (optional): the bias gradient
 };
 
 // sum over the 16 lanes of a DPP row of their partial sums p0..p3 of four outputs: lane m gets output m & 3
@@ -417,7 +418,7 @@ extern "C" __global__ __launch_bounds__(2 * X_G) void s2g_k_lstm64_stack_bwd(S2G
     w01[rr] = *reinterpret_cast<const f2*>(whh + (16 * m + rr) * X_H + 4 * R);
     w23[rr] = *reinterpret_cast<const f2*>(whh + (16 * m + rr) * X_H + 4 * R + 2);
   }
-  float dc = 0.0f;
+  float dc = 0.0f, bsum = 0.0f;
   float n_x[X_PF], n_gi[X_PF], n_gf[X_PF], n_gg[X_PF], n_go[X_PF], n_c[X_PF], n_cp[X_PF];
   if (grp == 0) {
     const float* __restrict__ dh_in = a.dh_top;
@@ -444,6 +445,7 @@ extern "C" __global__ __launch_bounds__(2 * X_G) void s2g_k_lstm64_stack_bwd(S2G
   const float mine0 = gate == 0 ? di : gate == 1 ? df : gate == 2 ? dg : dO;  \
   const float mine = live ? mine0 : 0.0f;                                     \
   ds[grp][(tick + 1) & 1][wpos] = mine;                                       \
+  bsum += mine;                                                               \
   if (live) delta[(r0 + t) * X_G + gate * X_H + u] = mine;
     const float* px = dh_in + u;
     const size_t sx = X_H;
@@ -495,6 +497,7 @@ extern "C" __global__ __launch_bounds__(2 * X_G) void s2g_k_lstm64_stack_bwd(S2G
   }
 #undef XB_FETCH
 #undef XB_CELL
+  if (a.bias_part[layer]) a.bias_part[layer][(size_t)n * X_G + gate * X_H + u] = bsum;
   for (size_t e = (size_t)len * X_G + j; e < (size_t)T * X_G; e += X_G) delta[r0 * X_G + e] = 0.0f;
 }
 

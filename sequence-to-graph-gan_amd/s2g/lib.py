@@ -44,7 +44,7 @@ class S2GLstm64Stack(ctypes.Structure):
 
 class S2GLstm64StackBwd(ctypes.Structure):
     _fields_ = [("dh_top", P), ("whh", P * 2), ("wih1", P), ("gates", P * 2), ("cst", P * 2), ("mask0", P),
-                ("delta", P * 2)]
+                ("delta", P * 2), ("bias_part", P * 2)]
 
 
 class S2GReduce(ctypes.Structure):

@@ -138,41 +138,47 @@ class _LstmStack:
         products run on its streams, layer 1's on one and layer 0's on the other; the caller joins them."""
         p, dev, rows = self.p.views, self.device, B * T
 
-        def weight_grads(l, delta, sc):
+        def weight_grads(l, delta, sc, bias_part=None):
             s = saved[l]
             _tn(ptr(delta), G4X, G4X, ptr(s["inp"]), HID, HID, rows, g[f"lstm.weight_ih_l{l}"], sc, accumulate)
             _tn(ptr(delta), G4X, G4X, ptr(s["hout"]), HID, HID, rows, g[f"lstm.weight_hh_l{l}"], sc, accumulate,
                 segT=T, shift=True)
-            ops.colsum(delta, rows, G4X, G4X, g[f"lstm.bias_ih_l{l}"], sc, accumulate=accumulate)
+            if bias_part is not None:      # the sweep already summed delta over time: B rows instead of B T
+                ops.colsum(bias_part, B, G4X, G4X, g[f"lstm.bias_ih_l{l}"], sc, accumulate=accumulate)
+            else:
+                ops.colsum(delta, rows, G4X, G4X, g[f"lstm.bias_ih_l{l}"], sc, accumulate=accumulate)
 
         fused = None
         if self.layers == 2:
             # both reverse sweeps in one launch; layer 0's incoming gradient never leaves the chip
             fused = [torch.empty(rows, G4X, device=dev) for _ in range(2)]
+            bparts = [torch.empty(B, G4X, device=dev) for _ in range(2)]
             st = S2GLstm64StackBwd()
             st.dh_top, st.wih1, st.mask0 = ptr(dh), ptr(p["lstm.weight_ih_l1"]), ptr(saved[0]["mask"])
             for l in range(2):
                 st.whh[l], st.gates[l], st.cst[l], st.delta[l] = (ptr(p[f"lstm.weight_hh_l{l}"]), ptr(saved[l]["gates"]),
                                                                 ptr(saved[l]["cst"]), ptr(fused[l]))
+                st.bias_part[l] = ptr(bparts[l])
             call("s2g_lstm64_stack_bwd", ctypes.byref(st), ptr(lengths), B, T, stream_ptr())
             if fan is not None:
                 fan.fork_ev[1].record()
                 for l, stream, sc in ((1, fan.b, fan.scratch_b), (0, fan.c, fan.scratch_c)):
                     with ops.on_stream(stream):
                         stream.wait_event(fan.fork_ev[1])
-                        weight_grads(l, fused[l], sc)
+                        weight_grads(l, fused[l], sc, bparts[l])
                 dinp = torch.empty(rows, HID, device=dev)
                 ops.linear_bwd_dx(fused[0], p["lstm.weight_ih_l0"], dinp, scratch)
                 return dinp
         for l in reversed(range(self.layers)):
             s = saved[l]
+            bpart = None
             if fused is not None:
-                delta = fused[l]
+                delta, bpart = fused[l], bparts[l]
             else:
                 delta = torch.empty(rows, G4X, device=dev)
                 call("s2g_lstm64_bwd", ptr(dh), ptr(p[f"lstm.weight_hh_l{l}"]), ptr(lengths), B, T, ptr(s["gates"]),
                      ptr(s["cst"]), ptr(delta), stream_ptr())
-            weight_grads(l, delta, scratch)
+            weight_grads(l, delta, scratch, bpart)
             if fused is not None and l > 0:
                 continue                  # the sweep below already took delta W_ih (times the mask) on chip
             dinp = torch.empty(rows, HID, device=dev)
