@@ -357,6 +357,15 @@ typedef struct S2GLstm64Stack {
   float* hout[3];
   const float* mask[3];
   float* hdrop[3];
+  /* token mode (tokens != NULL; pin0 unused): layer 0's input part of step t is tab[token_t] + tabl[label of the
+   * sequence], tab [V, 256] = emb W_ih0[:, :32]^T + b_ih0 + b_hh0, tabl [n_classes, 256] = label_emb W_ih0[:, 32:]^T:
+   * what the lookup branch of RelaxedEmbedding followed by the concat and the LSTM's input product compute
+   * (wgan.py:39-42, 107-111), without the [rows, 64] and [rows, 256] intermediates */
+  const int* tokens;
+  const float* tab;
+  const long long* labels;
+  const float* tabl;
+  int V, n_classes;
 } S2GLstm64Stack;
 int s2g_lstm64_stack_fwd(const S2GLstm64Stack* st, int layers, const int* lengths, int nseq, int T, void* stream);
 /* its autograd: dh_in [rows, 64] = gradient reaching every h_t from above -> delta [rows, 256], the gradient of
@@ -388,6 +397,15 @@ int s2g_embed_concat(const int* tokens, const float* emb, int V, const long long
 long s2g_embed_grad_tokens_scratch(long rows, int V);
 int s2g_embed_grad_tokens(const int* tokens, const int* lengths, int T, long rows, int V, const float* dx, float* demb,
                           int accumulate, float* part, void* stream);
+/* the same two-stage ordered sum for any [rows, width] matrix x (row stride ld, width a multiple of 32):
+ * out [V, width] = sum over live rows with token v of x[row]; part: s2g_embed_grad_tokens_scratch(rows, V) * width / 32
+ * floats.  With x = the gate gradients of LSTM layer 0 this is all the token path of wgan.py:107-111 needs for the
+ * gradients of W_ih0 and of the embedding (both are products of these [V, 256] sums with small matrices). */
+int s2g_bucket_rows_by_token(const int* tokens, const int* lengths, int T, long rows, int V, const float* x, int ld,
+                             int width, float* out, float* part, void* stream);
+/* out [n_classes, width] = sum over sequences with label l (ascending) of x[n] (x [B, width], width <= 1024) */
+int s2g_bucket_rows_by_label(const long long* labels, int B, int n_classes, const float* x, int width, float* out,
+                             void* stream);
 int s2g_embed_grad_labels(const long long* labels, const int* lengths, int T, int B, int n_classes, const float* dx,
                           float* dlab, int accumulate, float* part, void* stream);
 /* Attention pooling + output Linear of the critic (wgan.py:82-89, 116-118) over the first Tp = max(lengths) steps:

@@ -138,9 +138,15 @@ struct S2GLstm64Stack {    // mirrors include/s2g.h
   float* hout[3];           // [rows, 64] outputs (optional below the top layer)
   const float* mask[3];     // [rows, 64] dropout multiplier between layer l and l + 1 (optional)
   float* hdrop[3];          // [rows, 64] mask * h: the saved input of layer l + 1 (optional)
+  // token mode (tokens != null, pin0 unused): layer 0's input part is looked up, tab[token_t] + tabl[label_n]
+  const int* tokens;        // [rows]
+  const float* tab;         // [V, 256] = emb W_ih0[:, :32]^T + b_ih0 + b_hh0
+  const long long* labels;  // [sequences]
+  const float* tabl;        // [n_classes, 256] = label_emb W_ih0[:, 32:]^T
+  int V, n_classes;
 };
 
-template <int NL>
+template <int NL, bool TOK>
 __global__ __launch_bounds__(X_G * NL) void s2g_k_lstm64_stack_fwd(S2GLstm64Stack a, const int* __restrict__ lengths,
                                                                    int T) {
   __shared__ __attribute__((aligned(16))) float hs[NL][2][X_H];   // h of layer l, double buffered
@@ -175,11 +181,23 @@ __global__ __launch_bounds__(X_G * NL) void s2g_k_lstm64_stack_fwd(S2GLstm64Stac
     for (int g = 0; g < 4; ++g)
 #pragma unroll
       for (int k = 0; k < 8; ++k) w[g][k] = *reinterpret_cast<const f2*>(whh + (g * X_H + unit) * X_H + 16 * q + 2 * k);
-    const float* __restrict__ pin = a.pin0;
+    // token mode: the input part of step t is row token_t of a [V, 256] table (L2 resident) plus a per-sequence
+    // constant; the tokens travel in a ring of their own, X_PF steps ahead of the table rows they select
+    const float* __restrict__ pin = TOK ? a.tab : a.pin0;
+    const int* __restrict__ tokens = a.tokens;
+    const int vmax = a.V - 1;
+    float lbias = 0.0f;
+    if (TOK) lbias = a.tabl[(size_t)min(max((int)a.labels[n], 0), a.n_classes - 1) * X_G + row];
     float nx[X_PF];
+    int tk[X_PF];
 #pragma unroll
     for (int i = 0; i < X_PF; ++i) {
-      nx[i] = pin[(r0 + min(i, lastrow)) * X_G + row];
+      if (TOK) {
+        nx[i] = pin[(size_t)min(max(tokens[r0 + min(i, lastrow)], 0), vmax) * X_G + row];
+        tk[i] = tokens[r0 + min(i + X_PF, lastrow)];
+      } else {
+        nx[i] = pin[(r0 + min(i, lastrow)) * X_G + row];
+      }
       mk[i] = pm[(size_t)min(i, lastrow) * sm];
     }
     __syncthreads();
@@ -190,7 +208,7 @@ __global__ __launch_bounds__(X_G * NL) void s2g_k_lstm64_stack_fwd(S2GLstm64Stac
         const bool live = t < len;
         f2 p[4] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
         x_slice_fma(w, hs[0][t & 1] + 16 * q, p);
-        const float s = nx[i] + quad_gate_sum(p[0].x + p[0].y, p[1].x + p[1].y, p[2].x + p[2].y, p[3].x + p[3].y, q);
+        const float s = (nx[i] + lbias) + quad_gate_sum(p[0].x + p[0].y, p[1].x + p[1].y, p[2].x + p[2].y, p[3].x + p[3].y, q);
         const float g = fmaf(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(kact * s)), actA, actB);
         if (live && gates) gates[(r0 + t) * X_G + row] = g;
         const float gi = quad_bcast<0>(g), gf = quad_bcast<1>(g), gg = quad_bcast<2>(g), go = quad_bcast<3>(g);
@@ -206,7 +224,12 @@ __global__ __launch_bounds__(X_G * NL) void s2g_k_lstm64_stack_fwd(S2GLstm64Stac
             if (hdrop) hdrop[(r0 + t) * X_H + unit] = hx;
           }
         }
-        nx[i] = pin[(r0 + min(t + X_PF, lastrow)) * X_G + row];
+        if (TOK) {
+          nx[i] = pin[(size_t)min(max(tk[i], 0), vmax) * X_G + row];
+          tk[i] = tokens[r0 + min(t + 2 * X_PF, lastrow)];
+        } else {
+          nx[i] = pin[(r0 + min(t + X_PF, lastrow)) * X_G + row];
+        }
         mk[i] = pm[(size_t)min(t + X_PF, lastrow) * sm];
         __syncthreads();
       }
@@ -526,47 +549,87 @@ extern "C" __global__ void s2g_k_embed_concat(const int* __restrict__ tokens, co
 // chunk's table goes to part[chunk][V * 32].  Stage 2 (s2g_k_embed_grad_final) adds the chunks in ascending order.
 #define EG_CHUNK 512
 #define EG_GROUPS 4
+#define EG_BATCH 32
 extern "C" __global__ __launch_bounds__(32 * EG_GROUPS) void s2g_k_embed_grad_tokens_part(
     const int* __restrict__ tokens, const int* __restrict__ lengths, int T, long rows, int V,
-    const float* __restrict__ dx, float* __restrict__ part) {
+    const float* __restrict__ dx, int ld, int chunk, float* __restrict__ part) {
+  // blockIdx.y: a slice of 32 columns of dx (row stride ld); part [chunk][slice][V * 32]
   extern __shared__ float eg_tab[];      // [EG_GROUPS][V * 32]
   const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+  dx += blockIdx.y * 32;
   const int n = V * 32;
   for (int i = threadIdx.x; i < EG_GROUPS * n; i += 32 * EG_GROUPS) eg_tab[i] = 0.0f;
   __syncthreads();
   float* tab = eg_tab + g * n;
-  const long r0 = (long)blockIdx.x * EG_CHUNK + (long)g * (EG_CHUNK / EG_GROUPS);
-  const long r1 = min(r0 + EG_CHUNK / EG_GROUPS, rows);
-  for (long rb = r0; rb < r1; rb += 8) {
-    // eight rows' loads first (independent), then their additions in ascending row order
-    float v[8];
-    int tk[8];
+  const long r0 = (long)blockIdx.x * chunk + (long)g * (chunk / EG_GROUPS);     // chunk: a multiple of EG_BATCH EG_GROUPS
+  const long r1 = min(r0 + chunk / EG_GROUPS, rows);
+  // (sequence, step) of the row in hand, advanced by increments: a 64-bit division per row cost more than
+  // everything else in this loop together
+  const int nseq = (int)(rows / T);
+  int sq = (int)(min(r0, rows - 1) / T), st = (int)(min(r0, rows - 1) % T);
+  for (long rb = r0; rb < r1; rb += EG_BATCH) {
+    // a batch of rows' loads first (independent: the loop is bound by bytes in flight, two waves per CU), then
+    // their additions in ascending row order
+    float v[EG_BATCH];
+    int tk[EG_BATCH];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < EG_BATCH; ++k) {
+      // every load unconditional (a load in the arm of a select or behind && becomes a branch, and the join
+      // waits for all loads in flight: one memory round trip per row)
       const long r = min(rb + k, rows - 1);
-      const bool live = rb + k < r1 && (int)(r % T) < lengths[r / T];
-      tk[k] = live ? min(max(tokens[r], 0), V - 1) : -1;
-      v[k] = dx[r * 64 + c];
+      const int len = lengths[min(sq, nseq - 1)];
+      const int tv = tokens[r];
+      v[k] = dx[r * ld + c];
+      const bool live = (rb + k < r1) & (st < len);
+      tk[k] = live ? min(max(tv, 0), V - 1) : -1;
+      const bool wrap = st + 1 == T;
+      st = wrap ? 0 : st + 1;
+      sq += wrap ? 1 : 0;
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
+    for (int k = 0; k < EG_BATCH; ++k)
       if (tk[k] >= 0) tab[tk[k] * 32 + c] += v[k];
   }
   __syncthreads();
-  float* out = part + (size_t)blockIdx.x * n;
+  float* out = part + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * n;
   for (int i = threadIdx.x; i < n; i += 32 * EG_GROUPS)
     out[i] = ((eg_tab[i] + eg_tab[n + i]) + eg_tab[2 * n + i]) + eg_tab[3 * n + i];
 }
 
 // out[i] (+)= part[0][i] + part[1][i] + ... (ascending), i < n
+// (blockIdx.y = column slice; out row v = i / 32 has stride ldo)
 extern "C" __global__ __launch_bounds__(256) void s2g_k_embed_grad_final(const float* __restrict__ part, int nchunks,
-                                                                         int n, float* __restrict__ out,
+                                                                         int n, float* __restrict__ out, int ldo,
                                                                          int accumulate) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
+  const int nsl = gridDim.y, sl = blockIdx.y;
+  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+  int k = 0;
+  for (; k + 3 < nchunks; k += 4) {      // four chunks' loads in flight; one fixed order of additions
+    s0 += part[((size_t)k * nsl + sl) * n + i];
+    s1 += part[((size_t)(k + 1) * nsl + sl) * n + i];
+    s2 += part[((size_t)(k + 2) * nsl + sl) * n + i];
+    s3 += part[((size_t)(k + 3) * nsl + sl) * n + i];
+  }
+  for (; k < nchunks; ++k) s0 += part[((size_t)k * nsl + sl) * n + i];
+  const float s = (s0 + s1) + (s2 + s3);
+  float* o = out + (size_t)(i >> 5) * ldo + sl * 32 + (i & 31);
+  *o = accumulate ? *o + s : s;
+}
+
+// out[l][c] = sum over sequences n with label l (ascending) of x[n][c]; one workgroup per class, thread = column
+extern "C" __global__ void s2g_k_bucket_rows_by_label(const long long* __restrict__ labels, int B,
+                                                      const float* __restrict__ x, int W, float* __restrict__ out) {
+  const int l = blockIdx.x, c = threadIdx.x;
+  if (c >= W) return;
   float s = 0.0f;
-  for (int k = 0; k < nchunks; ++k) s += part[(size_t)k * n + i];
-  out[i] = accumulate ? out[i] + s : s;
+#pragma unroll 8
+  for (int b = 0; b < B; ++b) {          // unconditional loads: eight rows in flight
+    const float v = x[(size_t)b * W + c];
+    s += labels[b] == l ? v : 0.0f;
+  }
+  out[(size_t)l * W + c] = s;
 }
 
 // gradient of the label half: dlab[l] (+)= sum over sequences with label l and live rows of dx[row][32:64].

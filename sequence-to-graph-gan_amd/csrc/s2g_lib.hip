@@ -557,17 +557,23 @@ int s2g_lstm64_fwd(const float* pin, const float* whh, const int* lengths, int n
   return LAUNCH_OK();
 }
 int s2g_lstm64_stack_fwd(const S2GLstm64Stack* st, int layers, const int* lengths, int nseq, int T, void* stream) {
-  if (!st || (layers != 2 && layers != 3) || nseq <= 0 || T <= 0 || !st->pin0) return -1;
+  if (!st || (layers != 2 && layers != 3) || nseq <= 0 || T <= 0) return -1;
+  const bool tok = st->tokens != nullptr;
+  if (tok ? (!st->tab || !st->labels || !st->tabl || st->V <= 0 || st->n_classes <= 0) : !st->pin0) return -1;
   for (int l = 0; l < layers; ++l) {
     if (!st->whh[l]) return -1;
     if (l > 0 && (!st->wih[l] || !st->bsum[l])) return -1;
     if (st->mask[l] && (l + 1 >= layers || !st->hdrop[l])) return -1;
   }
   if (!st->hout[layers - 1]) return -1;
-  if (layers == 2)
-    hipLaunchKernelGGL(s2g_k_lstm64_stack_fwd<2>, dim3(nseq), dim3(X_G * 2), 0, ST(stream), *st, lengths, T);
+  if (layers == 2 && tok)
+    hipLaunchKernelGGL((s2g_k_lstm64_stack_fwd<2, true>), dim3(nseq), dim3(X_G * 2), 0, ST(stream), *st, lengths, T);
+  else if (layers == 2)
+    hipLaunchKernelGGL((s2g_k_lstm64_stack_fwd<2, false>), dim3(nseq), dim3(X_G * 2), 0, ST(stream), *st, lengths, T);
+  else if (tok)
+    hipLaunchKernelGGL((s2g_k_lstm64_stack_fwd<3, true>), dim3(nseq), dim3(X_G * 3), 0, ST(stream), *st, lengths, T);
   else
-    hipLaunchKernelGGL(s2g_k_lstm64_stack_fwd<3>, dim3(nseq), dim3(X_G * 3), 0, ST(stream), *st, lengths, T);
+    hipLaunchKernelGGL((s2g_k_lstm64_stack_fwd<3, false>), dim3(nseq), dim3(X_G * 3), 0, ST(stream), *st, lengths, T);
   return LAUNCH_OK();
 }
 int s2g_lstm64_bwd(const float* dh_in, const float* whh, const int* lengths, int nseq, int T, const float* gates,
@@ -595,9 +601,26 @@ long s2g_embed_grad_tokens_scratch(long rows, int V) {
   if (rows <= 0 || V <= 0) return -1;
   return ((rows + EG_CHUNK - 1) / EG_CHUNK) * (long)V * 32;
 }
+static int bucket_rows_by_token(const int* tokens, const int* lengths, int T, long rows, int V, const float* x, int ld,
+                                int width, float* out, int ldo, int accumulate, float* part, void* stream);
 int s2g_embed_grad_tokens(const int* tokens, const int* lengths, int T, long rows, int V, const float* dx, float* demb,
                           int accumulate, float* part, void* stream) {
+  return bucket_rows_by_token(tokens, lengths, T, rows, V, dx, 64, 32, demb, 32, accumulate, part, stream);
+}
+int s2g_bucket_rows_by_token(const int* tokens, const int* lengths, int T, long rows, int V, const float* x, int ld,
+                             int width, float* out, float* part, void* stream) {
+  return bucket_rows_by_token(tokens, lengths, T, rows, V, x, ld, width, out, width, 0, part, stream);
+}
+int s2g_bucket_rows_by_label(const long long* labels, int B, int n_classes, const float* x, int width, float* out,
+                             void* stream) {
+  if (!labels || !x || !out || B <= 0 || n_classes <= 0 || width <= 0 || width > 1024) return -1;
+  hipLaunchKernelGGL(s2g_k_bucket_rows_by_label, dim3(n_classes), dim3(width), 0, ST(stream), labels, B, x, width, out);
+  return LAUNCH_OK();
+}
+static int bucket_rows_by_token(const int* tokens, const int* lengths, int T, long rows, int V, const float* dx, int ld,
+                                int width, float* demb, int ldo, int accumulate, float* part, void* stream) {
   if (!tokens || !lengths || !dx || !demb || !part || T <= 0 || rows <= 0 || V <= 0) return -1;
+  if (width <= 0 || width % 32 || ld < width || ldo < width) return -1;
   const size_t lds = (size_t)EG_GROUPS * V * 32 * sizeof(float);   // four tables of V x 32 floats in LDS
   if (lds > 160 * 1024) return -1;                                 // V <= 320
   static bool attr_done = false;
@@ -606,11 +629,16 @@ int s2g_embed_grad_tokens(const int* tokens, const int* lengths, int T, long row
                                   160 * 1024));
     attr_done = true;
   }
-  const int nchunks = (int)((rows + EG_CHUNK - 1) / EG_CHUNK);
-  hipLaunchKernelGGL(s2g_k_embed_grad_tokens_part, dim3(nchunks), dim3(32 * EG_GROUPS), lds, ST(stream), tokens, lengths,
-                     T, rows, V, dx, part);
-  hipLaunchKernelGGL(s2g_k_embed_grad_final, dim3(cdiv((long)V * 32, 256)), dim3(256), 0, ST(stream), part, nchunks,
-                     V * 32, demb, accumulate);
+  const int nsl = width / 32;
+  // rows per workgroup: about one workgroup per CU over all column slices (a workgroup zeroes and flushes whole
+  // tables, so short chunks of wide matrices are all overhead); never below EG_CHUNK, the unit the scratch is sized by
+  long chunk = ((rows * nsl / 256 + EG_CHUNK - 1) / EG_CHUNK) * EG_CHUNK;
+  chunk = chunk < EG_CHUNK ? EG_CHUNK : (chunk > 16 * EG_CHUNK ? 16 * EG_CHUNK : chunk);
+  const int nchunks = (int)((rows + chunk - 1) / chunk);
+  hipLaunchKernelGGL(s2g_k_embed_grad_tokens_part, dim3(nchunks, nsl), dim3(32 * EG_GROUPS), lds, ST(stream), tokens,
+                     lengths, T, rows, V, dx, ld, (int)chunk, part);
+  hipLaunchKernelGGL(s2g_k_embed_grad_final, dim3(cdiv((long)V * 32, 256), nsl), dim3(256), 0, ST(stream), part, nchunks,
+                     V * 32, demb, ldo, accumulate);
   return LAUNCH_OK();
 }
 int s2g_embed_grad_labels(const long long* labels, const int* lengths, int T, int B, int n_classes, const float* dx,

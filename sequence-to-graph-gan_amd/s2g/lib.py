@@ -39,7 +39,8 @@ class S2GAttn(ctypes.Structure):
 
 
 class S2GLstm64Stack(ctypes.Structure):
-    _fields_ = [("pin0", P)] + [(k, P * 3) for k in ("whh", "wih", "bsum", "gates", "cst", "hout", "mask", "hdrop")]
+    _fields_ = ([("pin0", P)] + [(k, P * 3) for k in ("whh", "wih", "bsum", "gates", "cst", "hout", "mask", "hdrop")]
+                + [("tokens", P), ("tab", P), ("labels", P), ("tabl", P), ("V", I), ("n_classes", I)])
 
 
 class S2GLstm64StackBwd(ctypes.Structure):
@@ -121,6 +122,8 @@ SIGNATURES = {
     "s2g_embed_grad_tokens_scratch": [L, I],
     "s2g_embed_grad_tokens": [P, P, I, L, I, P, P, I, P, P],
     "s2g_embed_grad_labels": [P, P, I, I, I, P, P, I, P, P],
+    "s2g_bucket_rows_by_token": [P, P, I, L, I, P, I, I, P, P, P],
+    "s2g_bucket_rows_by_label": [P, I, I, P, I, P, P],
     "s2g_attnpool_fwd": [P, P, P, P, P, I, I, I, P, P, P, P],
     "s2g_attnpool_bwd": [P, P, P, P, P, P, I, I, I, P, P, P],
     "s2g_wasserstein_loss": [P, I, P, P, P],

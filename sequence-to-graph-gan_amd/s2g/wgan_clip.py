@@ -65,6 +65,7 @@ class _Fan:
         self.c, self.scratch_c = torch.cuda.Stream(device=device), ops.Scratch(device)
         self.fork_ev = [torch.cuda.Event() for _ in range(2)]
         self.join_ev = [torch.cuda.Event() for _ in range(2)]
+        self.deferred = None
 
     def join(self) -> None:
         """The current stream waits for everything queued on the two streams so far."""
@@ -81,11 +82,15 @@ class _LstmStack:
         self.p, self.layers, self.device = params, layers, device
         self.bsum = [torch.empty(G4X, device=device) for _ in range(layers)]
 
-    def forward(self, x: torch.Tensor, B: int, T: int, lengths: Optional[torch.Tensor],
-                masks: Optional[List[Optional[torch.Tensor]]], save: bool):
+    def forward(self, x: Optional[torch.Tensor], B: int, T: int, lengths: Optional[torch.Tensor],
+                masks: Optional[List[Optional[torch.Tensor]]], save: bool, tok=None):
+        """tok (2- and 3-layer stacks only, x unused): (tokens int32 [B, T], labels, embedding [V, 32], label
+        embedding [n_classes, 32]) -- layer 0's input part becomes a table lookup inside the sweep."""
         p, dev, rows = self.p.views, self.device, B * T
         if self.layers in (2, 3):
-            return self._forward_fused(x, B, T, lengths, masks, save)
+            return self._forward_fused(x, B, T, lengths, masks, save, tok)
+        if tok is not None:
+            raise S2GError("the token-table input needs a stack of 2 or 3 layers")
         inp, saved = x, []
         for l in range(self.layers):
             # b_ih + b_hh (adjacent views of the flat buffer) -> one bias for the batched input product
@@ -103,16 +108,27 @@ class _LstmStack:
             inp = hdrop if hdrop is not None else hout
         return hout, saved
 
-    def _forward_fused(self, x: torch.Tensor, B: int, T: int, lengths: Optional[torch.Tensor],
-                       masks: Optional[List[Optional[torch.Tensor]]], save: bool):
-        """All layers in one sweep (s2g_lstm64_stack_fwd): only layer 0 takes a batched input product."""
+    def _forward_fused(self, x: Optional[torch.Tensor], B: int, T: int, lengths: Optional[torch.Tensor],
+                       masks: Optional[List[Optional[torch.Tensor]]], save: bool, tok=None):
+        """All layers in one sweep (s2g_lstm64_stack_fwd): only layer 0 takes a batched input product, or, for
+        token inputs, two small tables: x_t W_ih0^T = (emb W_ih0[:, :32]^T)[token_t] + (lab_emb W_ih0[:, 32:]^T)[label]."""
         p, dev, rows, NL = self.p.views, self.device, B * T, self.layers
         for l in range(NL):
             ops.reduce_slabs(p[f"lstm.bias_ih_l{l}"], G4X, 2, 1, G4X, self.bsum[l])
-        pin = torch.empty(rows, G4X, device=dev)
-        ops.linear_fwd(x, p["lstm.weight_ih_l0"], self.bsum[0], pin)
         st, saved, inp = S2GLstm64Stack(), [], x
-        st.pin0 = ptr(pin)
+        W0 = p["lstm.weight_ih_l0"]
+        if tok is not None:
+            tokens, labels, emb, lab_emb = tok
+            V, NC = emb.shape[0], lab_emb.shape[0]
+            tab, tabl = torch.empty(V, G4X, device=dev), torch.empty(NC, G4X, device=dev)
+            ops.gemm_raw(ptr(emb), EMB, 1, ptr(W0), 1, 2 * EMB, ptr(tab), G4X, V, G4X, EMB, bias=ptr(self.bsum[0]))
+            ops.gemm_raw(ptr(lab_emb), EMB, 1, ptr(W0, EMB), 1, 2 * EMB, ptr(tabl), G4X, NC, G4X, EMB)
+            st.tokens, st.tab, st.labels, st.tabl, st.V, st.n_classes = ptr(tokens), ptr(tab), ptr(labels), ptr(tabl), V, NC
+            keep = (tab, tabl)            # referenced until the launch below is queued
+        else:
+            pin = torch.empty(rows, G4X, device=dev)
+            ops.linear_fwd(x, W0, self.bsum[0], pin)
+            st.pin0 = ptr(pin)
         for l in range(NL):
             top = l + 1 == NL
             mask = masks[l] if (masks is not None and not top) else None
@@ -132,15 +148,19 @@ class _LstmStack:
         return hout, saved
 
     def backward(self, dh: torch.Tensor, saved, B: int, T: int, lengths: Optional[torch.Tensor], g: Dict[str, torch.Tensor],
-                 scratch: ops.Scratch, accumulate: bool, fan: Optional[_Fan] = None) -> torch.Tensor:
+                 scratch: ops.Scratch, accumulate: bool, fan: Optional[_Fan] = None, tok: bool = False):
         """dh [rows, 64]: gradient of the top layer's outputs.  Accumulates the LSTM parameter gradients into g
         and returns the gradient of the stack's input [rows, 64].  fan (two-layer stacks): the weight-gradient
-        products run on its streams, layer 1's on one and layer 0's on the other; the caller joins them."""
+        products run on its streams, layer 1's on one and layer 0's on the other; the caller joins them.
+        tok (the forward took token tables): layer 0's input-side gradients are the caller's (they follow from
+        token- and label-bucketed sums of its gate gradients); returns (gate gradients of layer 0 [rows, 256],
+        their per-sequence sums [B, 256]) instead."""
         p, dev, rows = self.p.views, self.device, B * T
 
         def weight_grads(l, delta, sc, bias_part=None):
             s = saved[l]
-            _tn(ptr(delta), G4X, G4X, ptr(s["inp"]), HID, HID, rows, g[f"lstm.weight_ih_l{l}"], sc, accumulate)
+            if not (tok and l == 0):
+                _tn(ptr(delta), G4X, G4X, ptr(s["inp"]), HID, HID, rows, g[f"lstm.weight_ih_l{l}"], sc, accumulate)
             _tn(ptr(delta), G4X, G4X, ptr(s["hout"]), HID, HID, rows, g[f"lstm.weight_hh_l{l}"], sc, accumulate,
                 segT=T, shift=True)
             if bias_part is not None:      # the sweep already summed delta over time: B rows instead of B T
@@ -161,11 +181,19 @@ class _LstmStack:
                 st.bias_part[l] = ptr(bparts[l])
             call("s2g_lstm64_stack_bwd", ctypes.byref(st), ptr(lengths), B, T, stream_ptr())
             if fan is not None:
-                fan.fork_ev[1].record()
-                for l, stream, sc in ((1, fan.b, fan.scratch_b), (0, fan.c, fan.scratch_c)):
-                    with ops.on_stream(stream):
-                        stream.wait_event(fan.fork_ev[1])
-                        weight_grads(l, fused[l], sc, bparts[l])
+                def fork():
+                    fan.fork_ev[1].record()
+                    for l, stream, sc in ((1, fan.b, fan.scratch_b), (0, fan.c, fan.scratch_c)):
+                        with ops.on_stream(stream):
+                            stream.wait_event(fan.fork_ev[1])
+                            weight_grads(l, fused[l], sc, bparts[l])
+
+                if tok:
+                    # the caller starts them once its bucketed sums are queued: those kernels need most of a CU's
+                    # LDS per workgroup and would wait for the CUs that the products' tiles hold
+                    fan.deferred = fork
+                    return fused[0], bparts[0]
+                fork()
                 dinp = torch.empty(rows, HID, device=dev)
                 ops.linear_bwd_dx(fused[0], p["lstm.weight_ih_l0"], dinp, scratch)
                 return dinp
@@ -181,6 +209,8 @@ class _LstmStack:
             weight_grads(l, delta, scratch, bpart)
             if fused is not None and l > 0:
                 continue                  # the sweep below already took delta W_ih (times the mask) on chip
+            if tok:
+                return fused[0], bparts[0]
             dinp = torch.empty(rows, HID, device=dev)
             ops.linear_bwd_dx(delta, p[f"lstm.weight_ih_l{l}"], dinp, scratch)
             if l > 0 and saved[l - 1]["mask"] is not None:
@@ -250,14 +280,23 @@ class ClipCriticEngine:
         rows = B * T
         if not 1 <= Tp <= T:
             raise S2GError("critic: the longest length must lie in [1, T]")
-        x = torch.empty(rows, 2 * EMB, device=dev)
-        if soft:
-            ops._chk(seq, name="sequence")
-            ops.gemm_raw(ptr(seq), self.V, 1, ptr(p["sequence_embedding.embed_layer.weight"]), EMB, 1, ptr(x), 2 * EMB,
-                         rows, EMB, self.V)
-        call("s2g_embed_concat", None if soft else ptr(seq), ptr(p["sequence_embedding.embed_layer.weight"]), self.V,
-             ptr(labels), ptr(p["label_embedding.weight"]), self.n_classes, T, rows, int(soft), ptr(x), stream_ptr())
-        out, saved = self.stack.forward(x, B, T, lengths, masks, save)
+        tok = (not soft) and self.layers in (2, 3)
+        if tok:
+            # tokens: embedding lookup, concat and layer 0's input product collapse into two small tables
+            x = None
+            out, saved = self.stack.forward(None, B, T, lengths, masks, save,
+                                            tok=(seq, labels, p["sequence_embedding.embed_layer.weight"],
+                                                 p["label_embedding.weight"]))
+        else:
+            x = torch.empty(rows, 2 * EMB, device=dev)
+            if soft:
+                ops._chk(seq, name="sequence")
+                ops.gemm_raw(ptr(seq), self.V, 1, ptr(p["sequence_embedding.embed_layer.weight"]), EMB, 1, ptr(x),
+                             2 * EMB, rows, EMB, self.V)
+            call("s2g_embed_concat", None if soft else ptr(seq), ptr(p["sequence_embedding.embed_layer.weight"]),
+                 self.V, ptr(labels), ptr(p["label_embedding.weight"]), self.n_classes, T, rows, int(soft), ptr(x),
+                 stream_ptr())
+            out, saved = self.stack.forward(x, B, T, lengths, masks, save)
         pre = torch.empty(rows, HID, device=dev)
         ops.linear_fwd(out, p["attention.attn.weight"], p["attention.attn.bias"], pre)
         weights, pooled = torch.empty(B, T, device=dev), torch.empty(B, HID, device=dev)
@@ -265,7 +304,7 @@ class ClipCriticEngine:
             dval = torch.empty(B, device=dev)
         call("s2g_attnpool_fwd", ptr(pre), ptr(out), ptr(p["attention.context_vector.weight"]), ptr(p["linear.weight"]),
              ptr(p["linear.bias"]), B, T, Tp, ptr(weights), ptr(pooled), ptr(dval), stream_ptr())
-        state = dict(seq=seq, soft=soft, labels=labels, lengths=lengths, B=B, T=T, Tp=Tp, x=x, out=out, a=pre,
+        state = dict(seq=seq, soft=soft, tok=tok, labels=labels, lengths=lengths, B=B, T=T, Tp=Tp, x=x, out=out, a=pre,
                      weights=weights, pooled=pooled, lstm=saved) if save else None
         return dval, state
 
@@ -300,8 +339,34 @@ class ClipCriticEngine:
         # d(out) += d(pre) Wa
         ops.gemm_raw(ptr(dpre), HID, 1, ptr(p["attention.attn.weight"]), HID, 1, ptr(dout), HID, rows, HID, HID,
                      accumulate=True)
-        dx = self.stack.backward(dout, st["lstm"], B, T, st["lengths"], g, sc, accumulate, fan)
         ge = g["sequence_embedding.embed_layer.weight"]
+        if st["tok"]:
+            # S [V, 256] / Sl [n_classes, 256]: layer 0's gate gradients summed per token / per label; the
+            # gradients of W_ih0, of the embedding and of the label embedding are small products of them
+            delta0, bpart0 = self.stack.backward(dout, st["lstm"], B, T, st["lengths"], g, sc, accumulate, fan, tok=True)
+            lens = st["lengths"]
+            if lens is None:
+                lens = torch.full((B,), T, dtype=torch.int32, device=dev)
+            V, NC = self.V, self.n_classes
+            part = sc.get(int(get().s2g_embed_grad_tokens_scratch(rows, V)) * (G4X // 32))
+            S, Sl = torch.empty(V, G4X, device=dev), torch.empty(NC, G4X, device=dev)
+            call("s2g_bucket_rows_by_token", ptr(st["seq"]), ptr(lens), T, rows, V, ptr(delta0), G4X, G4X, ptr(S),
+                 ptr(part), stream_ptr())
+            call("s2g_bucket_rows_by_label", ptr(st["labels"]), B, NC, ptr(bpart0), G4X, ptr(Sl), stream_ptr())
+            if fan is not None:
+                fan.deferred()
+                fan.deferred = None
+            emb, lab, W0 = p["sequence_embedding.embed_layer.weight"], p["label_embedding.weight"], p["lstm.weight_ih_l0"]
+            gW0 = g["lstm.weight_ih_l0"]
+            ops.gemm_raw(ptr(S), 1, G4X, ptr(emb), EMB, 1, ptr(gW0), 2 * EMB, G4X, EMB, V, accumulate=accumulate)
+            ops.gemm_raw(ptr(Sl), 1, G4X, ptr(lab), EMB, 1, ptr(gW0, EMB), 2 * EMB, G4X, EMB, NC, accumulate=accumulate)
+            ops.gemm_raw(ptr(S), G4X, 1, ptr(W0), 2 * EMB, 1, ptr(ge), EMB, V, EMB, G4X, accumulate=accumulate)
+            ops.gemm_raw(ptr(Sl), G4X, 1, ptr(W0, EMB), 2 * EMB, 1, ptr(g["label_embedding.weight"]), EMB, NC, EMB, G4X,
+                         accumulate=accumulate)
+            if fan is not None:
+                fan.join()
+            return
+        dx = self.stack.backward(dout, st["lstm"], B, T, st["lengths"], g, sc, accumulate, fan)
         if st["soft"]:
             _tn(ptr(st["seq"]), self.V, self.V, ptr(dx), 2 * EMB, EMB, rows, ge, sc, accumulate)
         else:
