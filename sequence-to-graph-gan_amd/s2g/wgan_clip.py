@@ -65,7 +65,6 @@ class _Fan:
         self.c, self.scratch_c = torch.cuda.Stream(device=device), ops.Scratch(device)
         self.fork_ev = [torch.cuda.Event() for _ in range(2)]
         self.join_ev = [torch.cuda.Event() for _ in range(2)]
-        self.deferred = None
 
     def join(self) -> None:
         """The current stream waits for everything queued on the two streams so far."""
@@ -181,19 +180,13 @@ class _LstmStack:
                 st.bias_part[l] = ptr(bparts[l])
             call("s2g_lstm64_stack_bwd", ctypes.byref(st), ptr(lengths), B, T, stream_ptr())
             if fan is not None:
-                def fork():
-                    fan.fork_ev[1].record()
-                    for l, stream, sc in ((1, fan.b, fan.scratch_b), (0, fan.c, fan.scratch_c)):
-                        with ops.on_stream(stream):
-                            stream.wait_event(fan.fork_ev[1])
-                            weight_grads(l, fused[l], sc, bparts[l])
-
+                fan.fork_ev[1].record()
+                for l, stream, sc in ((1, fan.b, fan.scratch_b), (0, fan.c, fan.scratch_c)):
+                    with ops.on_stream(stream):
+                        stream.wait_event(fan.fork_ev[1])
+                        weight_grads(l, fused[l], sc, bparts[l])
                 if tok:
-                    # the caller starts them once its bucketed sums are queued: those kernels need most of a CU's
-                    # LDS per workgroup and would wait for the CUs that the products' tiles hold
-                    fan.deferred = fork
                     return fused[0], bparts[0]
-                fork()
                 dinp = torch.empty(rows, HID, device=dev)
                 ops.linear_bwd_dx(fused[0], p["lstm.weight_ih_l0"], dinp, scratch)
                 return dinp
@@ -353,9 +346,6 @@ class ClipCriticEngine:
             call("s2g_bucket_rows_by_token", ptr(st["seq"]), ptr(lens), T, rows, V, ptr(delta0), G4X, G4X, ptr(S),
                  ptr(part), stream_ptr())
             call("s2g_bucket_rows_by_label", ptr(st["labels"]), B, NC, ptr(bpart0), G4X, ptr(Sl), stream_ptr())
-            if fan is not None:
-                fan.deferred()
-                fan.deferred = None
             emb, lab, W0 = p["sequence_embedding.embed_layer.weight"], p["label_embedding.weight"], p["lstm.weight_ih_l0"]
             gW0 = g["lstm.weight_ih_l0"]
             ops.gemm_raw(ptr(S), 1, G4X, ptr(emb), EMB, 1, ptr(gW0), 2 * EMB, G4X, EMB, V, accumulate=accumulate)

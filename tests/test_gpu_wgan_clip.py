@@ -150,3 +150,110 @@ def test_embedding_gradients_match_index_add(B, T, V):
         k = 1 + accumulate
         assert (de.cpu().double() - k * ref_e).abs().max() <= 1e-5 * ref_e.abs().max()
         assert (dl.cpu().double() - k * ref_l).abs().max() <= 1e-5 * ref_l.abs().max()
+
+
+@pytest.mark.parametrize("B,T,V,W", [(5, 37, 175, 256), (128, 1024, 175, 256), (7, 50, 33, 64)])
+def test_bucketed_row_sums_match_index_add(B, T, V, W):
+    """s2g_bucket_rows_by_token / _by_label against index_add in float64 (live rows only; the benchmark's shape
+    spans many row chunks and all eight column slices)."""
+    from s2g.lib import call, get
+    from s2g.ops import ptr, stream_ptr
+    g = common.gen(6)
+    tokens = torch.randint(0, V, (B, T), generator=g, dtype=torch.int32)
+    lengths = torch.randint(1, T + 1, (B,), generator=g, dtype=torch.int32)
+    lengths[0] = T
+    labels = torch.randint(0, 2, (B,), generator=g)
+    x = torch.randn(B * T, W, generator=g)
+    live = (torch.arange(T)[None, :] < lengths[:, None]).reshape(-1)
+    ref = torch.zeros(V, W, dtype=torch.float64).index_add_(0, tokens.reshape(-1)[live].long(), x[live].double())
+    xb = torch.randn(B, W, generator=g)
+    ref_l = torch.zeros(2, W, dtype=torch.float64).index_add_(0, labels, xb.double())
+    part = torch.empty(get().s2g_embed_grad_tokens_scratch(B * T, V) * (W // 32), device=DEV)
+    out, out_l = torch.full((V, W), 7.0, device=DEV), torch.full((2, W), 7.0, device=DEV)
+    tk, ln, xd, xbd, lb = tokens.to(DEV), lengths.to(DEV), x.to(DEV), xb.to(DEV), labels.to(DEV)
+    call("s2g_bucket_rows_by_token", ptr(tk), ptr(ln), T, B * T, V, ptr(xd), W, W, ptr(out), ptr(part), stream_ptr())
+    call("s2g_bucket_rows_by_label", ptr(lb), B, 2, ptr(xbd), W, ptr(out_l), stream_ptr())
+    torch.cuda.synchronize()
+    assert (out.cpu().double() - ref).abs().max() <= 1e-5 * ref.abs().max()
+    assert (out_l.cpu().double() - ref_l).abs().max() <= 1e-5 * ref_l.abs().max()
+
+
+@pytest.mark.parametrize("layers,use_mask", [(2, True), (2, False), (3, False)])
+def test_stack_sweeps_match_the_per_layer_sweeps(layers, use_mask):
+    """s2g_lstm64_stack_fwd (and, for two layers, s2g_lstm64_stack_bwd) against one s2g_lstm64_fwd / _bwd launch
+    per layer with the batched products in between, on a ragged batch: same saved planes, outputs and gate
+    gradients to 1e-5 (the products are summed in another order)."""
+    import ctypes
+    from s2g.lib import S2GLstm64Stack, S2GLstm64StackBwd, call
+    from s2g import ops
+    from s2g.ops import ptr, stream_ptr
+    B, T, H, G4 = 9, 45, 64, 256
+    g = common.gen(77 + layers)
+    lengths = torch.randint(1, T + 1, (B,), generator=g, dtype=torch.int32)
+    lengths[0], lengths[1] = T, 1
+    rows = B * T
+    dev = torch.device(DEV)
+    W = [dict(ih=(0.2 * torch.randn(G4, H, generator=g)).to(dev), hh=(0.2 * torch.randn(G4, H, generator=g)).to(dev),
+              b=(0.1 * torch.randn(G4, generator=g)).to(dev)) for _ in range(layers)]
+    x = torch.randn(rows, H, generator=g).to(dev)
+    masks = [((torch.rand(rows, H, generator=g) > 0.3).float() / 0.7).to(dev) if use_mask and l + 1 < layers else None
+             for l in range(layers)]
+    ln = lengths.to(dev)
+    # per-layer path
+    ref, inp = [], x
+    for l in range(layers):
+        pin = torch.empty(rows, G4, device=dev)
+        ops.linear_fwd(inp, W[l]["ih"], W[l]["b"], pin)
+        gates, cst, hout = torch.empty(rows, G4, device=dev), torch.empty(rows, H, device=dev), torch.empty(rows, H, device=dev)
+        hdrop = torch.empty(rows, H, device=dev) if masks[l] is not None else None
+        call("s2g_lstm64_fwd", ptr(pin), ptr(W[l]["hh"]), ptr(ln), B, T, ptr(gates), ptr(cst), ptr(hout), ptr(masks[l]),
+             ptr(hdrop), stream_ptr())
+        ref.append(dict(gates=gates, cst=cst, hout=hout, hdrop=hdrop))
+        inp = hdrop if hdrop is not None else hout
+    # one sweep
+    pin0 = torch.empty(rows, G4, device=dev)
+    ops.linear_fwd(x, W[0]["ih"], W[0]["b"], pin0)
+    st, got = S2GLstm64Stack(), []
+    st.pin0 = ptr(pin0)
+    for l in range(layers):
+        o = dict(gates=torch.empty(rows, G4, device=dev), cst=torch.empty(rows, H, device=dev),
+                 hout=torch.full((rows, H), 9.0, device=dev),
+                 hdrop=torch.full((rows, H), 9.0, device=dev) if masks[l] is not None else None)
+        st.whh[l], st.gates[l], st.cst[l], st.hout[l] = ptr(W[l]["hh"]), ptr(o["gates"]), ptr(o["cst"]), ptr(o["hout"])
+        st.mask[l], st.hdrop[l] = ptr(masks[l]), ptr(o["hdrop"])
+        if l:
+            st.wih[l], st.bsum[l] = ptr(W[l]["ih"]), ptr(W[l]["b"])
+        got.append(o)
+    call("s2g_lstm64_stack_fwd", ctypes.byref(st), layers, ptr(ln), B, T, stream_ptr())
+    torch.cuda.synchronize()
+    live = (torch.arange(T)[None, :] < lengths[:, None]).reshape(-1).to(dev)
+    for l in range(layers):
+        for k in ("gates", "cst"):                      # saved planes: rows of live steps only
+            assert_close(got[l][k][live], ref[l][k][live], 1e-5, f"layer {l} {k}", atol=1e-6)
+        assert_close(got[l]["hout"], ref[l]["hout"], 1e-5, f"layer {l} hout", atol=1e-6)      # zeros beyond the length
+        if masks[l] is not None:
+            assert_close(got[l]["hdrop"], ref[l]["hdrop"], 1e-5, f"layer {l} hdrop", atol=1e-6)
+    if layers != 2:
+        return
+    dh = torch.randn(rows, H, generator=g).to(dev)
+    d1 = torch.empty(rows, G4, device=dev)
+    call("s2g_lstm64_bwd", ptr(dh), ptr(W[1]["hh"]), ptr(ln), B, T, ptr(ref[1]["gates"]), ptr(ref[1]["cst"]), ptr(d1),
+         stream_ptr())
+    dinp = d1 @ W[1]["ih"]
+    if masks[0] is not None:
+        dinp = dinp * masks[0]
+    d0 = torch.empty(rows, G4, device=dev)
+    call("s2g_lstm64_bwd", ptr(dinp.contiguous()), ptr(W[0]["hh"]), ptr(ln), B, T, ptr(ref[0]["gates"]), ptr(ref[0]["cst"]),
+         ptr(d0), stream_ptr())
+    sb = S2GLstm64StackBwd()
+    f = [torch.full((rows, G4), 9.0, device=dev) for _ in range(2)]
+    bp = [torch.empty(B, G4, device=dev) for _ in range(2)]
+    sb.dh_top, sb.wih1, sb.mask0 = ptr(dh), ptr(W[1]["ih"]), ptr(masks[0])
+    for l in range(2):
+        sb.whh[l], sb.gates[l], sb.cst[l], sb.delta[l], sb.bias_part[l] = (ptr(W[l]["hh"]), ptr(ref[l]["gates"]),
+                                                                           ptr(ref[l]["cst"]), ptr(f[l]), ptr(bp[l]))
+    call("s2g_lstm64_stack_bwd", ctypes.byref(sb), ptr(ln), B, T, stream_ptr())
+    torch.cuda.synchronize()
+    for l, d in ((1, d1), (0, d0)):
+        assert_close(f[l], d, 1e-4, f"delta{l}", atol=1e-6)
+        assert_close(bp[l], d.view(B, T, G4).sum(1), 1e-4, f"bias sums {l}", atol=1e-5)
