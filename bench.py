@@ -348,7 +348,26 @@ def main():
     # The step runs on a non-blocking stream of its own: the CU-masked second stream of the critic is a
     # blocking stream, i.e. it would synchronise implicitly with every launch on the NULL stream.
     torch.cuda.synchronize()
+    prewarm = 0
     with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+        if world == 1:
+            # A freshly leased box enqueues slowly for its first tens of seconds (host side: 7 ms per step against
+            # 4 ms a minute later, same binary), which makes the step launch-bound.  Untimed blocks of steps run
+            # until the host's enqueue time per step stops improving (at least 3 blocks, at most ~12 s); the W
+            # warmup steps and the K timed steps follow unchanged.  Single-process runs only: ranks must stay in
+            # lockstep, and the driver's multi-rank runs follow its one-rank run on the same node.
+            best, stale, t_pre = float("inf"), 0, time.perf_counter()
+            while time.perf_counter() - t_pre < 12.0:
+                t_blk = time.perf_counter()
+                for k in range(25):
+                    one_step(prewarm + k)
+                enq = (time.perf_counter() - t_blk) / 25
+                torch.cuda.synchronize()
+                prewarm += 25
+                stale = 0 if enq < 0.95 * best else stale + 1
+                best = min(best, enq)
+                if prewarm >= 75 and stale >= 2:
+                    break
         for k in range(a.warmup):
             one_step(k)
         ev.clear()
@@ -443,6 +462,7 @@ def main():
                        "global_batch": B_PER_GPU * world, "seq_len": L, "parallelism": f"dp{world}"},
             "ms_per_critic_iteration_est": ms_per_step / (N_CRITIC + 0.3),
             "host_enqueue_ms_per_step": t_host / a.steps * 1e3,
+            "prewarm_steps": prewarm,
             "roofline": {"bound": "mfma", "kernel": dom,
                          "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,

@@ -588,35 +588,43 @@ extern "C" __global__ __launch_bounds__(1024) void s2g_k_critic_loss(const float
 // The four small kernels between sweep A and sweep B of a critic iteration in ONE single-workgroup
 // launch: head forward on [real B | fake B | interp B], the loss terms and d(out) of
 // s2g_k_critic_loss, d(hT) for all 3B rows and the fc gradients over the first 2B rows (the interp
-// third's d(out) = e0 only seeds the penalty).  Phases talk through global memory + __syncthreads
-// (one workgroup = one CU, so its own stores are visible to it after the barrier).
+// third's d(out) = e0 only seeds the penalty).  Phases talk through LDS (out, d(out) and the fc weight are
+// mirrored there; dynamic LDS of (18 B + 3 S2G_H) floats): the kernel sits between two sweeps of every critic
+// iteration, and each phase that re-read the previous one's global stores paid a memory round trip.
 extern "C" __global__ __launch_bounds__(1024) void s2g_k_critic_head(
     const float* __restrict__ hT, const float* __restrict__ W, const float* __restrict__ bias,
     const long long* __restrict__ labels, int B, float inv_n, float inv_wsum, float w0, float w1,
     float* __restrict__ out, float* __restrict__ dout, float* __restrict__ losses, float* __restrict__ dhT,
     float* __restrict__ dW, float* __restrict__ db) {
   __shared__ float red[3][16];
+  extern __shared__ float ch_lds[];
+  float* s_out = ch_lds;                 // [3B][3]
+  float* s_dout = ch_lds + 9 * B;        // [3B][3]
+  float* s_W = ch_lds + 18 * B;          // [3][S2G_H]
   const int tid = threadIdx.x, nt = blockDim.x;
+  const int y = tid < B ? (int)labels[tid] : 0;            // fetched beside the head's operands
+  if (tid < 3 * S2G_H) s_W[tid] = W[tid];
   for (int i = tid; i < 3 * B * 3; i += nt) {
     const int n = i / 3, j = i - 3 * n;
     float s = bias[j];
     for (int k = 0; k < S2G_H; ++k) s = fmaf(W[j * S2G_H + k], hT[n * S2G_H + k], s);
     out[i] = s;
+    s_out[i] = s;
   }
   __syncthreads();
   float lr = 0.f, lf = 0.f, lce = 0.f;
   if (tid < B) {
-    const int b = tid, y = (int)labels[b];
+    const int b = tid;
     float l, d0, d1;
-    const float* o = out + b * 3;
+    const float* o = s_out + b * 3;
     ce_on_probs(o[1], o[2], y, w0, w1, inv_wsum, l, d0, d1);
-    dout[b * 3 + 0] = -inv_n; dout[b * 3 + 1] = 0.5f * d0; dout[b * 3 + 2] = 0.5f * d1;
+    s_dout[b * 3 + 0] = -inv_n; s_dout[b * 3 + 1] = 0.5f * d0; s_dout[b * 3 + 2] = 0.5f * d1;
     lr = -o[0] * inv_n; lce = 0.5f * l;
-    o = out + (B + b) * 3;
+    o = s_out + (B + b) * 3;
     ce_on_probs(o[1], o[2], y, w0, w1, inv_wsum, l, d0, d1);
-    dout[(B + b) * 3 + 0] = inv_n; dout[(B + b) * 3 + 1] = 0.5f * d0; dout[(B + b) * 3 + 2] = 0.5f * d1;
+    s_dout[(B + b) * 3 + 0] = inv_n; s_dout[(B + b) * 3 + 1] = 0.5f * d0; s_dout[(B + b) * 3 + 2] = 0.5f * d1;
     lf = o[0] * inv_n; lce += 0.5f * l;
-    dout[(2 * B + b) * 3 + 0] = 1.0f; dout[(2 * B + b) * 3 + 1] = 0.0f; dout[(2 * B + b) * 3 + 2] = 0.0f;
+    s_dout[(2 * B + b) * 3 + 0] = 1.0f; s_dout[(2 * B + b) * 3 + 1] = 0.0f; s_dout[(2 * B + b) * 3 + 2] = 0.0f;
   }
   lr = row16_sum(lr); lr += __shfl_xor(lr, 16); lr += __shfl_xor(lr, 32);
   lf = row16_sum(lf); lf += __shfl_xor(lf, 16); lf += __shfl_xor(lf, 32);
@@ -628,9 +636,10 @@ extern "C" __global__ __launch_bounds__(1024) void s2g_k_critic_head(
     for (int w = 0; w < (nt >> 6); ++w) s += red[tid][w];
     losses[tid] = s;
   }
+  for (int i = tid; i < 3 * B * 3; i += nt) dout[i] = s_dout[i];
   for (int i = tid; i < 3 * B * S2G_H; i += nt) {
     const int n = i / S2G_H, k = i - n * S2G_H;
-    dhT[i] = fmaf(dout[n * 3 + 2], W[2 * S2G_H + k], fmaf(dout[n * 3 + 1], W[S2G_H + k], dout[n * 3] * W[k]));
+    dhT[i] = fmaf(s_dout[n * 3 + 2], s_W[2 * S2G_H + k], fmaf(s_dout[n * 3 + 1], s_W[S2G_H + k], s_dout[n * 3] * s_W[k]));
   }
   // fc gradients over the 2B real + fake rows: 4 threads per (j, k), quad-summed
   const int q = tid & 3, o4 = tid >> 2;
@@ -638,7 +647,7 @@ extern "C" __global__ __launch_bounds__(1024) void s2g_k_critic_head(
     const int j = o4 / S2G_H, k = o4 - j * S2G_H;
     float s = 0.0f, sb = 0.0f;
     for (int n = q; n < 2 * B; n += 4) {
-      const float d = dout[n * 3 + j];
+      const float d = s_dout[n * 3 + j];
       s = fmaf(d, hT[n * S2G_H + k], s);
       sb += d;
     }

@@ -411,7 +411,13 @@ int s2g_critic_head(const float* hT, const float* W, const float* bias, const lo
                     float* dW, float* db, void* stream) {
   if (!hT || !W || !bias || !labels || !out || !dout || !losses || !dhT || !dW || !db || B <= 0 || B > 1024)
     return -1;
-  hipLaunchKernelGGL(s2g_k_critic_head, dim3(1), dim3(1024), 0, ST(stream), hT, W, bias, labels, B, inv_n, inv_wsum,
+  const size_t lds = (size_t)(18 * B + 3 * S2G_H) * sizeof(float);     // out, d(out) and the fc weight mirrored in LDS
+  static bool attr_done = false;
+  if (!attr_done) {                                                    // B = 1024 needs 74 KB: above the default cap
+    S2G_CHECK(hipFuncSetAttribute((const void*)s2g_k_critic_head, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(s2g_k_critic_head, dim3(1), dim3(1024), lds, ST(stream), hT, W, bias, labels, B, inv_n, inv_wsum,
                      w0, w1, out, dout, losses, dhT, dW, db);
   return LAUNCH_OK();
 }
