@@ -646,10 +646,20 @@ extern "C" __global__ __launch_bounds__(1024) void s2g_k_critic_head(
   if (o4 < 3 * S2G_H) {
     const int j = o4 / S2G_H, k = o4 - j * S2G_H;
     float s = 0.0f, sb = 0.0f;
-    for (int n = q; n < 2 * B; n += 4) {
-      const float d = s_dout[n * 3 + j];
-      s = fmaf(d, hT[n * S2G_H + k], s);
-      sb += d;
+    // eight rows' loads of hT in flight, then their terms in the same ascending order (one row per iteration
+    // paid a cache round trip each: 2B / 4 of them in a row)
+    const int nlast = 2 * B - 1;
+    for (int nb = q; nb < 2 * B; nb += 32) {
+      float hv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) hv[u] = hT[min(nb + 4 * u, nlast) * S2G_H + k];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int n = nb + 4 * u;
+        const float d = n < 2 * B ? s_dout[min(n, nlast) * 3 + j] : 0.0f;
+        s = n < 2 * B ? fmaf(d, hv[u], s) : s;
+        sb += d;
+      }
     }
     s = quad_sum(s);
     sb = quad_sum(sb);
