@@ -257,3 +257,32 @@ def test_stack_sweeps_match_the_per_layer_sweeps(layers, use_mask):
     for l, d in ((1, d1), (0, d0)):
         assert_close(f[l], d, 1e-4, f"delta{l}", atol=1e-6)
         assert_close(bp[l], d.view(B, T, G4).sum(1), 1e-4, f"bias sums {l}", atol=1e-5)
+
+
+def test_one_stream_and_overlapped_critic_steps_agree():
+    """critic_step with everything on the caller's stream (overlap = False: the fake pass accumulates into the real
+    pass's gradients, no side streams) against the default schedule (fake pass and weight-gradient products on side
+    streams, two gradient buffers added at the end): same loss, gradients and updated weights to 1e-5, on a ragged
+    batch with dropout masks."""
+    V, B, T = 175, 12, 64
+    tokens, labels, lengths = common.batch(1710, B, T, vocab=V, min_len=1)
+    g = common.gen(1720)
+    noise = torch.randint(0, V, (B, 100), generator=g)
+    U = torch.rand((B, 100, V), generator=g)
+    m_real = ((torch.rand((B * T, 64), generator=g) > 0.3).float() / 0.7).to(DEV)
+    m_fake = ((torch.rand((B * 100, 64), generator=g) > 0.3).float() / 0.7).to(DEV)
+    res = []
+    for overlap in (False, True):
+        D, G, _, _ = engines(1701, V, dropout=0.3)
+        D.overlap = overlap
+        fake = G.forward(noise.to(torch.int32).to(DEV), labels.to(DEV), 0.5, U=U.to(DEV))
+        loss = D.critic_step(tokens.to(torch.int32).to(DEV).contiguous(), labels.to(DEV), lengths.to(torch.int32).to(DEV),
+                             int(lengths.max()), fake, 2e-4, 0.5, 0.999, 0.1, masks_real=[m_real, None],
+                             masks_fake=[m_fake, None])
+        torch.cuda.synchronize()
+        res.append((float(loss), {n: v.clone() for n, v in D.grads.views.items()},
+                    {n: v.clone() for n, v in D.params.views.items()}))
+    assert abs(res[0][0] - res[1][0]) <= 1e-6 * max(1.0, abs(res[0][0]))
+    for n in res[0][1]:
+        assert_close(res[1][1][n], res[0][1][n], 1e-5, f"grad {n}", atol=1e-9)
+        assert_close(res[1][2][n], res[0][2][n], 1e-5, n)
