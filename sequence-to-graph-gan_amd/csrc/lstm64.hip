@@ -146,26 +146,35 @@ struct S2GLstm64Stack {    // mirrors include/s2g.h
   int V, n_classes;
 };
 
-template <int NL, bool TOK>
-__global__ __launch_bounds__(X_G * NL) void s2g_k_lstm64_stack_fwd(S2GLstm64Stack a, const int* __restrict__ lengths,
-                                                                   int T) {
+// SPLIT (two layers only): a third group of 256 threads takes layer 1's input product W_ih1 x_t + b off the cell
+// group's hands one tick ahead (through LDS), and the cell group runs two ticks behind layer 0: three waves per SIMD
+// with 32 packed FMAs each per tick instead of two with 32 and 64.
+template <int NL, bool TOK, bool SPLIT>
+__global__ __launch_bounds__(X_G * (NL + (SPLIT ? 1 : 0))) void s2g_k_lstm64_stack_fwd(S2GLstm64Stack a,
+                                                                                       const int* __restrict__ lengths,
+                                                                                       int T) {
+  static_assert(!SPLIT || NL == 2, "the split arrangement is written for two layers");
   __shared__ __attribute__((aligned(16))) float hs[NL][2][X_H];   // h of layer l, double buffered
   __shared__ __attribute__((aligned(16))) float xs[NL][2][X_H];   // xs[l]: input of layer l + 1
+  __shared__ float xp[2][X_G];                                    // SPLIT: W_ih1 x_t + b, double buffered
   const int n = blockIdx.x;
-  const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8), j = threadIdx.x & (X_G - 1);
+  const int wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8), j = threadIdx.x & (X_G - 1);
+  const bool producer = SPLIT && wg == 2;
+  const int grp = producer ? 1 : wg;                              // the layer this group works for
   const int unit = j >> 2, q = j & 3;
   const int row = q * X_H + unit;
   const int len = lengths ? min(max(lengths[n], 0), T) : T;
-  const int nticks = len > 0 ? ((len + NL - 1 + X_PF - 1) / X_PF) * X_PF : 0;
+  const int nticks = len > 0 ? ((len + NL - 1 + (SPLIT ? 1 : 0) + X_PF - 1) / X_PF) * X_PF : 0;
   const size_t r0 = (size_t)n * T;
   const float kact = (q == 2) ? -2.8853900817779268f : -1.4426950408889634f;
   const float actA = (q == 2) ? 2.0f : 1.0f, actB = (q == 2) ? -1.0f : 0.0f;
   const int lastrow = max(len - 1, 0);
-  for (int e = threadIdx.x; e < NL * 2 * X_H; e += X_G * NL) { (&hs[0][0][0])[e] = 0.0f; (&xs[0][0][0])[e] = 0.0f; }
-  float* __restrict__ gates = a.gates[grp];
-  float* __restrict__ cst = a.cst[grp];
-  float* __restrict__ hout = a.hout[grp];
-  float* __restrict__ hdrop = a.hdrop[grp];
+  for (int e = threadIdx.x; e < NL * 2 * X_H; e += blockDim.x) { (&hs[0][0][0])[e] = 0.0f; (&xs[0][0][0])[e] = 0.0f; }
+  for (int e = threadIdx.x; e < 2 * X_G; e += blockDim.x) (&xp[0][0])[e] = 0.0f;
+  float* __restrict__ gates = producer ? nullptr : a.gates[grp];
+  float* __restrict__ cst = producer ? nullptr : a.cst[grp];
+  float* __restrict__ hout = producer ? nullptr : a.hout[grp];
+  float* __restrict__ hdrop = producer ? nullptr : a.hdrop[grp];
   const float* whh = a.whh[grp];
   const bool feeds = grp + 1 < NL;                                // a layer above reads this group's output
   const bool has_mask = feeds && a.mask[grp] != nullptr;
@@ -175,7 +184,23 @@ __global__ __launch_bounds__(X_G * NL) void s2g_k_lstm64_stack_fwd(S2GLstm64Stac
   const int sm = has_mask ? X_H : 0;
   float mk[X_PF];
   float c = 0.0f;
-  if (grp == 0) {
+  if (producer) {
+    // x_t of tick s - 1 (layer 0 wrote it during that tick) -> xp for the cell group's next tick
+    f2 wi[4][8];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) wi[g][k] = *reinterpret_cast<const f2*>(a.wih[1] + (g * X_H + unit) * X_H + 16 * q + 2 * k);
+    const float bias = a.bsum[1][row];
+    __syncthreads();
+    for (int tick = 0; tick < nticks; ++tick) {
+      const int t = tick - 1;
+      f2 px[4] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
+      x_slice_fma(wi, xs[0][t & 1] + 16 * q, px);
+      xp[t & 1][row] = bias + quad_gate_sum(px[0].x + px[0].y, px[1].x + px[1].y, px[2].x + px[2].y, px[3].x + px[3].y, q);
+      __syncthreads();
+    }
+  } else if (grp == 0) {
     f2 w[4][8];
 #pragma unroll
     for (int g = 0; g < 4; ++g)
@@ -242,23 +267,29 @@ __global__ __launch_bounds__(X_G * NL) void s2g_k_lstm64_stack_fwd(S2GLstm64Stac
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         wh[g][k] = *reinterpret_cast<const f2*>(whh + (g * X_H + unit) * X_H + 16 * q + 2 * k);
-        wi[g][k] = *reinterpret_cast<const f2*>(wih + (g * X_H + unit) * X_H + 16 * q + 2 * k);
+        if (!SPLIT) wi[g][k] = *reinterpret_cast<const f2*>(wih + (g * X_H + unit) * X_H + 16 * q + 2 * k);
       }
     const float bias = a.bsum[grp][row];
+    const int lag = SPLIT ? 2 : grp;                   // ticks behind layer 0
 #pragma unroll
-    for (int i = 0; i < X_PF; ++i) mk[i] = pm[(size_t)min(max(i - grp, 0), lastrow) * sm];
+    for (int i = 0; i < X_PF; ++i) mk[i] = pm[(size_t)min(max(i - lag, 0), lastrow) * sm];
     __syncthreads();
     for (int base = 0; base < nticks; base += X_PF) {
 #pragma unroll
       for (int i = 0; i < X_PF; ++i) {
-        const int t = base + i - grp;                  // this layer's time step at this tick
+        const int t = base + i - lag;                  // this layer's time step at this tick
         const bool live = t >= 0 && t < len;
         f2 ph[4] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
         f2 px[4] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
         x_slice_fma(wh, hs[grp][t & 1] + 16 * q, ph);
-        x_slice_fma(wi, xs[grp - 1][t & 1] + 16 * q, px);
-        const float s = bias + quad_gate_sum((ph[0].x + ph[0].y) + (px[0].x + px[0].y), (ph[1].x + ph[1].y) + (px[1].x + px[1].y),
-                                             (ph[2].x + ph[2].y) + (px[2].x + px[2].y), (ph[3].x + ph[3].y) + (px[3].x + px[3].y), q);
+        float s;
+        if (SPLIT) {
+          s = xp[t & 1][row] + quad_gate_sum(ph[0].x + ph[0].y, ph[1].x + ph[1].y, ph[2].x + ph[2].y, ph[3].x + ph[3].y, q);
+        } else {
+          x_slice_fma(wi, xs[grp - 1][t & 1] + 16 * q, px);
+          s = bias + quad_gate_sum((ph[0].x + ph[0].y) + (px[0].x + px[0].y), (ph[1].x + ph[1].y) + (px[1].x + px[1].y),
+                                   (ph[2].x + ph[2].y) + (px[2].x + px[2].y), (ph[3].x + ph[3].y) + (px[3].x + px[3].y), q);
+        }
         const float g = fmaf(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(kact * s)), actA, actB);
         if (live && gates) gates[(r0 + t) * X_G + row] = g;
         const float gi = quad_bcast<0>(g), gf = quad_bcast<1>(g), gg = quad_bcast<2>(g), go = quad_bcast<3>(g);

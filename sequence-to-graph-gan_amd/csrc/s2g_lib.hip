@@ -573,13 +573,13 @@ int s2g_lstm64_stack_fwd(const S2GLstm64Stack* st, int layers, const int* length
   }
   if (!st->hout[layers - 1]) return -1;
   if (layers == 2 && tok)
-    hipLaunchKernelGGL((s2g_k_lstm64_stack_fwd<2, true>), dim3(nseq), dim3(X_G * 2), 0, ST(stream), *st, lengths, T);
+    hipLaunchKernelGGL((s2g_k_lstm64_stack_fwd<2, true, true>), dim3(nseq), dim3(X_G * 3), 0, ST(stream), *st, lengths, T);
   else if (layers == 2)
-    hipLaunchKernelGGL((s2g_k_lstm64_stack_fwd<2, false>), dim3(nseq), dim3(X_G * 2), 0, ST(stream), *st, lengths, T);
+    hipLaunchKernelGGL((s2g_k_lstm64_stack_fwd<2, false, true>), dim3(nseq), dim3(X_G * 3), 0, ST(stream), *st, lengths, T);
   else if (tok)
-    hipLaunchKernelGGL((s2g_k_lstm64_stack_fwd<3, true>), dim3(nseq), dim3(X_G * 3), 0, ST(stream), *st, lengths, T);
+    hipLaunchKernelGGL((s2g_k_lstm64_stack_fwd<3, true, false>), dim3(nseq), dim3(X_G * 3), 0, ST(stream), *st, lengths, T);
   else
-    hipLaunchKernelGGL((s2g_k_lstm64_stack_fwd<3, false>), dim3(nseq), dim3(X_G * 3), 0, ST(stream), *st, lengths, T);
+    hipLaunchKernelGGL((s2g_k_lstm64_stack_fwd<3, false, false>), dim3(nseq), dim3(X_G * 3), 0, ST(stream), *st, lengths, T);
   return LAUNCH_OK();
 }
 int s2g_lstm64_bwd(const float* dh_in, const float* whh, const int* lengths, int nseq, int T, const float* gates,
