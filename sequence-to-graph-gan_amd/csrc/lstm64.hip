@@ -447,25 +447,32 @@ __device__ __forceinline__ void x_slice_fma_t(const f2 (&w01)[16], const f2 (&w2
   pb += qb;
 }
 
-extern "C" __global__ __launch_bounds__(2 * X_G) void s2g_k_lstm64_stack_bwd(S2GLstm64StackBwd a,
+// Three groups of 256 threads: the top layer; a producer that turns the top layer's gate gradients of the previous
+// tick into W_ih1^T delta1_t (64 values through LDS); the lower layer's cell group two ticks behind the top layer
+// (three waves per SIMD with 32 packed FMAs each per tick instead of two with 32 and 64).
+extern "C" __global__ __launch_bounds__(3 * X_G) void s2g_k_lstm64_stack_bwd(S2GLstm64StackBwd a,
                                                                              const int* __restrict__ lengths, int T) {
   __shared__ __attribute__((aligned(16))) float ds[2][2][X_G];     // [group][buffer][gate row]
+  __shared__ float xq[2][X_H];                                     // W_ih1^T delta1_t, double buffered
   const int n = blockIdx.x;
-  const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8), j = threadIdx.x & (X_G - 1);
+  const int wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8), j = threadIdx.x & (X_G - 1);
+  const bool producer = wg == 2;
+  const int grp = producer ? 1 : wg;
   const int R = j >> 4, m = j & 15;
   const int u = 4 * R + (m & 3), gate = m >> 2;
   const int wpos = x_tpos(gate * X_H + u);
   const int len = lengths ? min(max(lengths[n], 0), T) : T;
-  const int nticks = len > 0 ? ((len + 1 + X_PF - 1) / X_PF) * X_PF : 0;
+  const int nticks = len > 0 ? ((len + 2 + X_PF - 1) / X_PF) * X_PF : 0;
   const int lastrow = max(len - 1, 0);
   const size_t r0 = (size_t)n * T;
-  for (int e = threadIdx.x; e < 2 * 2 * X_G; e += 2 * X_G) (&ds[0][0][0])[e] = 0.0f;
+  for (int e = threadIdx.x; e < 2 * 2 * X_G; e += blockDim.x) (&ds[0][0][0])[e] = 0.0f;
+  if (threadIdx.x < 2 * X_H) (&xq[0][0])[threadIdx.x] = 0.0f;
   const int layer = 1 - grp;
   const float* __restrict__ gates = a.gates[layer];
   const float* __restrict__ cst = a.cst[layer];
-  float* __restrict__ delta = a.delta[layer];
-  const float* whh = a.whh[layer];
-  // own recurrent weights: W_hh[16 m + rr][4R + o]
+  float* __restrict__ delta = producer ? nullptr : a.delta[layer];
+  const float* whh = producer ? a.wih1 : a.whh[layer];
+  // own weights, W[16 m + rr][4R + o]: W_hh of the group's layer; the producer holds W_ih of the top layer
   f2 w01[16], w23[16];
 #pragma unroll
   for (int rr = 0; rr < 16; ++rr) {
@@ -474,7 +481,17 @@ extern "C" __global__ __launch_bounds__(2 * X_G) void s2g_k_lstm64_stack_bwd(S2G
   }
   float dc = 0.0f, bsum = 0.0f;
   float n_x[X_PF], n_gi[X_PF], n_gf[X_PF], n_gg[X_PF], n_go[X_PF], n_c[X_PF], n_cp[X_PF];
-  if (grp == 0) {
+  if (producer) {
+    __syncthreads();
+    for (int tick = 0; tick < nticks; ++tick) {
+      // the top layer wrote delta1 of step len - tick into ds[0][tick & 1] during the previous tick
+      f2 xa = {0.0f, 0.0f}, xb = {0.0f, 0.0f};
+      x_slice_fma_t(w01, w23, ds[0][tick & 1], m, xa, xb);
+      const float above = row16_out_sum(xa, xb, m);
+      if (gate == 0) xq[tick & 1][u] = above;
+      __syncthreads();
+    }
+  } else if (grp == 0) {
     const float* __restrict__ dh_in = a.dh_top;
 #define XB_FETCH(i, t_)                                                       \
   {                                                                           \
@@ -520,29 +537,21 @@ extern "C" __global__ __launch_bounds__(2 * X_G) void s2g_k_lstm64_stack_bwd(S2G
       }
     }
   } else {
-    // W_ih of the layer above, same slicing: the gradient reaching this layer's h from above
-    f2 v01[16], v23[16];
-#pragma unroll
-    for (int rr = 0; rr < 16; ++rr) {
-      v01[rr] = *reinterpret_cast<const f2*>(a.wih1 + (16 * m + rr) * X_H + 4 * R);
-      v23[rr] = *reinterpret_cast<const f2*>(a.wih1 + (16 * m + rr) * X_H + 4 * R + 2);
-    }
     const bool has_mask = a.mask0 != nullptr;
     const float* px = has_mask ? a.mask0 + u : whh;        // without a mask: a harmless load, the value is not used
     const size_t sx = has_mask ? X_H : 0;
 #pragma unroll
-    for (int i = 0; i < X_PF; ++i) XB_FETCH(i, len - i)
+    for (int i = 0; i < X_PF; ++i) XB_FETCH(i, len + 1 - i)
     __syncthreads();
     for (int base = 0; base < nticks; base += X_PF) {
 #pragma unroll
       for (int i = 0; i < X_PF; ++i) {
-        const int tick = base + i, t = len - tick;         // one tick behind the layer above
+        const int tick = base + i, t = len + 1 - tick;     // two ticks behind the layer above (one behind the producer)
         const bool live = t >= 0 && t < len;
-        f2 pa = {0.0f, 0.0f}, pb = {0.0f, 0.0f}, xa = {0.0f, 0.0f}, xb = {0.0f, 0.0f};
+        f2 pa = {0.0f, 0.0f}, pb = {0.0f, 0.0f};
         x_slice_fma_t(w01, w23, ds[1][tick & 1], m, pa, pb);
-        x_slice_fma_t(v01, v23, ds[0][tick & 1], m, xa, xb);
         const float rec = row16_out_sum(pa, pb, m);
-        const float above = row16_out_sum(xa, xb, m);
+        const float above = xq[(tick - 1) & 1][u];         // written by the producer during the previous tick
         XB_CELL(fmaf(has_mask ? n_x[i] : 1.0f, above, rec))
         XB_FETCH(i, t - X_PF)
         __syncthreads();
@@ -551,6 +560,7 @@ extern "C" __global__ __launch_bounds__(2 * X_G) void s2g_k_lstm64_stack_bwd(S2G
   }
 #undef XB_FETCH
 #undef XB_CELL
+  if (producer) return;
   if (a.bias_part[layer]) a.bias_part[layer][(size_t)n * X_G + gate * X_H + u] = bsum;
   for (size_t e = (size_t)len * X_G + j; e < (size_t)T * X_G; e += X_G) delta[r0 * X_G + e] = 0.0f;
 }

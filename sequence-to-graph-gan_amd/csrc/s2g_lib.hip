@@ -592,7 +592,7 @@ int s2g_lstm64_stack_bwd(const S2GLstm64StackBwd* st, const int* lengths, int ns
   if (!st || nseq <= 0 || T <= 0 || !st->dh_top || !st->wih1) return -1;
   for (int l = 0; l < 2; ++l)
     if (!st->whh[l] || !st->gates[l] || !st->cst[l] || !st->delta[l]) return -1;
-  hipLaunchKernelGGL(s2g_k_lstm64_stack_bwd, dim3(nseq), dim3(2 * X_G), 0, ST(stream), *st, lengths, T);
+  hipLaunchKernelGGL(s2g_k_lstm64_stack_bwd, dim3(nseq), dim3(3 * X_G), 0, ST(stream), *st, lengths, T);
   return LAUNCH_OK();
 }
 int s2g_embed_concat(const int* tokens, const float* emb, int V, const long long* labels, const float* lab_emb,
