@@ -1,8 +1,10 @@
 // LSTM sweeps for the weight-clipping WGAN variant (reference wgan.py: nn.LSTM(64, 64, num_layers) in
 // Generator :58 and Discriminator :100, hidden_dim = 64) and its attention pooling (wgan.py:75-89).
-// One layer per launch over all its time steps, one workgroup of 256 threads per sequence: a thread owns one
-// gate row (forward: the four gates of a unit in one quad) / one gate block's slice of a column (reverse) with its
-// 64 recurrent weights in registers; the input part
+// Stacks of two or three layers run ALL layers in one sweep per direction (s2g_k_lstm64_stack_fwd / _bwd below:
+// one group of 256 threads per layer and, for two layers, a third group for the upper layer's input-side product).
+// Other depths: one layer per launch over all its time steps, one workgroup of 256 threads per sequence: a thread
+// owns one gate row (forward: the four gates of a unit in one quad) / one gate block's slice of a column (reverse)
+// with its 64 recurrent weights in registers; the input part
 // x_t W_ih^T + b_ih + b_hh of every step is a batched GEMM done beforehand (it does not depend on the
 // recurrence), and the weight gradients are batched GEMMs over the saved gate gradients afterwards.
 // Rows: sequence n owns rows [n * rows_per_seq, n * rows_per_seq + len_n) of every [rows, .] buffer; rows at or
