@@ -638,8 +638,18 @@ extern "C" __global__ __launch_bounds__(256) void s2g_k_bias_sums_final(
   const bool ok = i < 2 * S2G_G;
   const int layer = ok ? i / S2G_G : 0, j = ok ? i % S2G_G : 0;
   float s = 0.0f;
-  if (ok)
-    for (int z = w; z < nchunk; z += 4) s += part[layer * layer_stride + (long)z * S2G_G + j];
+  if (ok) {
+    // eight partial rows' loads in flight, added in the same ascending order (one load per iteration paid a cache
+    // round trip each: nchunk / 4 of them in a row, in a kernel that sits between two sweeps)
+    const float* pp = part + layer * layer_stride + j;
+    for (int zb = w; zb < nchunk; zb += 32) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = pp[(long)min(zb + 4 * k, nchunk - 1) * S2G_G];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s = zb + 4 * k < nchunk ? s + v[k] : s;
+    }
+  }
   red[w][l] = s;
   __syncthreads();
   if (w != 0 || !ok) return;
