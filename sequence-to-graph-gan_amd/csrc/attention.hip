@@ -321,12 +321,8 @@ template <int ND>
 static int attn_launch_fwd(const float* Q, const float* K, const float* V, const float* attn_mask, const float* pad_mask,
                            float* out, float* P, AttnDims dm, hipStream_t stream) {
   const size_t lds = attn_lds_bytes(dm.T);
-  static size_t set_for = 0;
-  if (lds > set_for) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&s2g_k_attn_fwd<ND>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
-    set_for = lds;
-  }
+  static S2GLdsCap lds_cap;
+  if (s2g_lds_cap(lds_cap, reinterpret_cast<const void*>(&s2g_k_attn_fwd<ND>), lds) != 0) return -2;
   hipLaunchKernelGGL((s2g_k_attn_fwd<ND>), dim3((dm.T + 15) / 16, dm.H, dm.N), dim3(256), lds, stream, Q, K, V, attn_mask,
                      pad_mask, out, P, dm);
   return hipGetLastError() == hipSuccess ? 0 : -2;
@@ -337,12 +333,8 @@ static int attn_launch_bwd(const float* Q, const float* K, const float* V, const
                            const float* P, const float* dO, float* dS, float* dQ, float* dK, float* dV, AttnDims dm,
                            hipStream_t stream) {
   const size_t lds = attn_lds_bytes(dm.T);
-  static size_t set_for = 0;
-  if (lds > set_for) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&s2g_k_attn_bwd_q<ND>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
-    set_for = lds;
-  }
+  static S2GLdsCap lds_cap;
+  if (s2g_lds_cap(lds_cap, reinterpret_cast<const void*>(&s2g_k_attn_bwd_q<ND>), lds) != 0) return -2;
   const dim3 grid((dm.T + 15) / 16, dm.H, dm.N);
   hipLaunchKernelGGL((s2g_k_attn_bwd_q<ND>), grid, dim3(256), lds, stream, K, V, attn_mask, pad_mask, P, dO, dS, dQ, dm);
   hipLaunchKernelGGL((s2g_k_attn_bwd_kv<ND>), grid, dim3(256), 0, stream, Q, P, dS, dO, dK, dV, dm);

@@ -811,12 +811,8 @@ extern "C" int s2g_launch_gemm_tall(const float* A, long lda, const float* B, lo
 #define S2G_TALL16_CASE(NT_)                                                                                   \
   if (nt16 <= NT_) {                                                                                           \
     const size_t lds = 2 * (TALL_ROWS * TALL16_ALD + 32 * (NT_ * 16 + ((NT_ & 1) ? 0 : 16))) * sizeof(float);  \
-    static bool attr_done = false;                                                                             \
-    if (!attr_done) {                                                                                          \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&s2g_k_gemm_tall16<NT_>),                          \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;  \
-      attr_done = true;                                                                                        \
-    }                                                                                                          \
+    static S2GLdsCap lds_cap;                                                                                      \
+    if (s2g_lds_cap(lds_cap, reinterpret_cast<const void*>(&s2g_k_gemm_tall16<NT_>), lds) != 0) return -2;         \
     hipLaunchKernelGGL((s2g_k_gemm_tall16<NT_>), grid, block, lds, stream, A, lda, B, ldb, C, ldc, M, N, K);   \
     return hipGetLastError() == hipSuccess ? 0 : -2;                                                           \
   }
@@ -1083,15 +1079,9 @@ extern "C" __global__ __launch_bounds__(64 * WS_WAVES) void s2g_k_generate_token
 extern "C" int s2g_launch_generate_tokens(const float* W, const float* X, const float* bias, const float* U,
                                           long long* tokens, int L, int V, int M, int K, unsigned long long seed,
                                           unsigned long long offset, hipStream_t stream) {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -2;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&s2g_k_generate_tokens),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2;
-    cus = prop.multiProcessorCount;
-  }
+  static S2GLdsCap lds_cap;
+  const int cus = s2g_device_cus();
+  if (cus <= 0 || s2g_lds_cap(lds_cap, reinterpret_cast<const void*>(&s2g_k_generate_tokens), 160 * 1024) != 0) return -2;
   const int tps = (V + 15) >> 4;
   // time steps per workgroup: as many as fill the 8 waves evenly and still give every CU a group
   int TS = 1;
@@ -1110,15 +1100,9 @@ extern "C" int s2g_launch_generate_tokens(const float* W, const float* X, const 
 extern "C" int s2g_launch_linear_wstream(const float* W, const float* X, const float* bias, float* Y, int N, int M,
                                          int K, int max_workgroups, hipStream_t stream) {
   const size_t lds = (size_t)K * WS_LD * sizeof(float);
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -2;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&s2g_k_linear_wstream),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2;
-    cus = prop.multiProcessorCount;
-  }
+  static S2GLdsCap lds_cap;
+  const int cus = s2g_device_cus();
+  if (cus <= 0 || s2g_lds_cap(lds_cap, reinterpret_cast<const void*>(&s2g_k_linear_wstream), 160 * 1024) != 0) return -2;
   int blocks = ((N >> 4) + WS_WAVES - 1) / WS_WAVES;
   const int cap = (max_workgroups > 0 && max_workgroups < cus) ? max_workgroups : cus;
   if (blocks > cap) blocks = cap;

@@ -103,12 +103,8 @@ extern "C" int s2g_launch_gemm_tall_bf16(const float* A, long lda, const float* 
 #define S2G_TALLB_CASE(NT_)                                                                              \
   if (nt <= NT_) {                                                                                       \
     const size_t lds = (size_t)16 * NT_ * TB_LD * sizeof(__bf16);                                        \
-    static bool attr_done = false;                                                                       \
-    if (!attr_done) {                                                                                    \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&s2g_k_gemm_tall_bf16<NT_>),                 \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2; \
-      attr_done = true;                                                                                  \
-    }                                                                                                    \
+    static S2GLdsCap lds_cap;                                                                                \
+    if (s2g_lds_cap(lds_cap, reinterpret_cast<const void*>(&s2g_k_gemm_tall_bf16<NT_>), lds) != 0) return -2; \
     hipLaunchKernelGGL((s2g_k_gemm_tall_bf16<NT_>), grid, block, lds, stream, A, lda, B, ldb, C, ldc, M, N, K); \
     return hipGetLastError() == hipSuccess ? 0 : -2;                                                     \
   }

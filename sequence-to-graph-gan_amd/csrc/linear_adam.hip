@@ -144,15 +144,9 @@ extern "C" int s2g_launch_linear_wgrad_adam(const float* dY, const float* A, flo
                                             float* gradW, int N, int B, int K, float b1, float b2, float eps,
                                             float step_size, float inv_sqrt_bc2, int max_workgroups,
                                             hipStream_t stream) {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -2;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&s2g_k_linear_wgrad_adam),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2;
-    cus = prop.multiProcessorCount;
-  }
+  static S2GLdsCap lds_cap;
+  const int cus = s2g_device_cus();
+  if (cus <= 0 || s2g_lds_cap(lds_cap, reinterpret_cast<const void*>(&s2g_k_linear_wgrad_adam), 160 * 1024) != 0) return -2;
   const size_t lds = ((size_t)LA_KH * LA_LD + 2 * LA_STAGE) * sizeof(float);
   const int nkh = K / LA_KH;
   const long items = (long)((N + LA_ROWS - 1) / LA_ROWS) * nkh;

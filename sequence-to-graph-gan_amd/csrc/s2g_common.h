@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 
 #define S2G_H 50          // critic hidden size (wgan_gp.py:394)
 #define S2G_G 200         // 4*H gate rows
@@ -144,3 +145,39 @@ __device__ __forceinline__ int pos13(int k) { return ((k / 13) << 4) + (k % 13);
     hipError_t _e = (expr);                               \
     if (_e != hipSuccess) return -(int)_e - 1000;         \
   } while (0)
+
+// ---- host helpers ----------------------------------------------------------------------------
+// A kernel's cap on dynamic LDS (hipFuncAttributeMaxDynamicSharedMemorySize) belongs to the DEVICE it was
+// set on: a process that drives several GPUs must raise it on each.  One S2GLdsCap per kernel remembers what
+// every device has been given; lds_cap() raises the cap of the current device when `bytes` exceeds that.
+struct S2GLdsCap {
+  std::mutex mu;
+  int set[64] = {0};
+};
+static inline int s2g_lds_cap(S2GLdsCap& c, const void* kernel, size_t bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -2;
+  std::lock_guard<std::mutex> lk(c.mu);
+  if (c.set[dev] < (int)bytes) {
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      return -2;
+    }
+    c.set[dev] = (int)bytes;
+  }
+  return 0;
+}
+// Compute units of the current device (cached per device).
+static inline int s2g_device_cus() {
+  static std::mutex mu;
+  static int cus[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!cus[dev]) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+    cus[dev] = prop.multiProcessorCount;
+  }
+  return cus[dev];
+}

@@ -412,11 +412,8 @@ int s2g_critic_head(const float* hT, const float* W, const float* bias, const lo
   if (!hT || !W || !bias || !labels || !out || !dout || !losses || !dhT || !dW || !db || B <= 0 || B > 1024)
     return -1;
   const size_t lds = (size_t)(18 * B + 3 * S2G_H) * sizeof(float);     // out, d(out) and the fc weight mirrored in LDS
-  static bool attr_done = false;
-  if (!attr_done) {                                                    // B = 1024 needs 74 KB: above the default cap
-    S2G_CHECK(hipFuncSetAttribute((const void*)s2g_k_critic_head, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-    attr_done = true;
-  }
+  static S2GLdsCap lds_cap;                                                // B = 1024 needs 74 KB: above the default cap
+  if (s2g_lds_cap(lds_cap, (const void*)s2g_k_critic_head, 80 * 1024) != 0) return -2;
   hipLaunchKernelGGL(s2g_k_critic_head, dim3(1), dim3(1024), lds, ST(stream), hT, W, bias, labels, B, inv_n, inv_wsum,
                      w0, w1, out, dout, losses, dhT, dW, db);
   return LAUNCH_OK();
@@ -626,15 +623,12 @@ int s2g_bucket_rows_by_label(const long long* labels, int B, int n_classes, cons
 static int bucket_rows_by_token(const int* tokens, const int* lengths, int T, long rows, int V, const float* dx, int ld,
                                 int width, float* demb, int ldo, int accumulate, float* part, void* stream) {
   if (!tokens || !lengths || !dx || !demb || !part || T <= 0 || rows <= 0 || V <= 0) return -1;
+  if (rows % T) return -1;                                         // rows = sequences x T: lengths[] is read per sequence
   if (width <= 0 || width % 32 || ld < width || ldo < width) return -1;
   const size_t lds = (size_t)EG_GROUPS * V * 32 * sizeof(float);   // four tables of V x 32 floats in LDS
   if (lds > 160 * 1024) return -1;                                 // V <= 320
-  static bool attr_done = false;
-  if (!attr_done) {
-    S2G_CHECK(hipFuncSetAttribute((const void*)s2g_k_embed_grad_tokens_part, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024));
-    attr_done = true;
-  }
+  static S2GLdsCap lds_cap;
+  if (s2g_lds_cap(lds_cap, (const void*)s2g_k_embed_grad_tokens_part, 160 * 1024) != 0) return -2;
   const int nsl = width / 32;
   // rows per workgroup: about one workgroup per CU over all column slices (a workgroup zeroes and flushes whole
   // tables, so short chunks of wide matrices are all overhead); never below EG_CHUNK, the unit the scratch is sized by
@@ -736,18 +730,8 @@ int s2g_graph_features(const int* tokens, const int* lengths, int n_seq, int L, 
   a.state_off = graph_state_off(V, a.ecap);
   if (a.state_off < 0) return -3;                             // the sequence's edge lists do not fit in LDS
   const int lds = graph_lds_layout(V, a.ecap, a.state_off).total;
-  static std::mutex mu;
-  static int lds_set[64] = {0};
-  int dev = 0;
-  S2G_CHECK(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 64) return -3;
-  {
-    std::lock_guard<std::mutex> lk(mu);
-    if (lds_set[dev] < lds) {
-      S2G_CHECK(hipFuncSetAttribute((const void*)s2g_k_graph_features, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-      lds_set[dev] = lds;
-    }
-  }
+  static S2GLdsCap lds_cap;
+  if (s2g_lds_cap(lds_cap, (const void*)s2g_k_graph_features, (size_t)lds) != 0) return -2;
   hipLaunchKernelGGL(s2g_k_graph_features, dim3(n_seq), dim3(GR_THREADS), lds, ST(stream), a);
   return LAUNCH_OK();
 }

@@ -231,14 +231,38 @@ def colsum(X: torch.Tensor, rows: int, cols: int, ld: int, out: torch.Tensor, sc
 
 
 # ----------------------------------------------------------------------------- random draws
+def _splitmix64(x: int) -> int:
+    m = 0xFFFFFFFFFFFFFFFF
+    x = (x + 0x9E3779B97F4A7C15) & m
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & m
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & m
+    return x ^ (x >> 31)
+
+
 class DeviceRng:
     """Seed and running offset of the library's counter-based generator (Philox4x32-10): every draw is a
     pure function of (seed, offset, position) and takes the next offset, so no generator state lives on
     the device.  Stands in for the reference's CPU-generator draws (wgan_gp.py:58, 228, 291), which no
     device generator reproduces; parity runs inject their noise instead."""
 
+    _instances = 0
+
     def __init__(self, seed: Optional[int] = None):
-        self.seed = (torch.initial_seed() if seed is None else int(seed)) & 0xFFFFFFFFFFFFFFFF
+        """seed None: torch.initial_seed() mixed with the number of default-seeded generators made so far in
+        this process and with the rank of the process, so that the engines of one process and the ranks of a
+        data-parallel run (all seeded alike by torch.manual_seed) draw from different streams.  An explicit
+        seed is taken as is (the draws are then a pure function of it: tests and replays rely on that)."""
+        if seed is None:
+            DeviceRng._instances += 1
+            rank = 0
+            try:
+                import torch.distributed as dist
+                if dist.is_available() and dist.is_initialized():
+                    rank = dist.get_rank()
+            except Exception:      # noqa: BLE001
+                rank = 0
+            seed = torch.initial_seed() ^ _splitmix64((DeviceRng._instances << 20) + rank + 1)
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         self.offset = 0
 
     def take(self):

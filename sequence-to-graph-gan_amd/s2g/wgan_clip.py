@@ -65,13 +65,22 @@ class _Fan:
         self.c, self.scratch_c = torch.cuda.Stream(device=device), ops.Scratch(device)
         self.fork_ev = [torch.cuda.Event() for _ in range(2)]
         self.join_ev = [torch.cuda.Event() for _ in range(2)]
+        self.keep: List[torch.Tensor] = []
+
+    def hold(self, *tensors) -> None:
+        """Tensors allocated on the caller's stream that the two streams read: kept referenced until join().
+        (Dropped earlier, the caching allocator hands their blocks to the caller stream's next allocation,
+        which may be written while the products queued here still read them.)"""
+        self.keep.extend(t for t in tensors if t is not None)
 
     def join(self) -> None:
-        """The current stream waits for everything queued on the two streams so far."""
+        """The current stream waits for everything queued on the two streams so far; what hold() kept is
+        released behind that wait (a later allocation on the current stream is ordered after the readers)."""
         cur = torch.cuda.current_stream()
         for stream, ev in zip((self.b, self.c), self.join_ev):
             ev.record(stream)
             cur.wait_event(ev)
+        self.keep.clear()
 
 
 class _LstmStack:
@@ -180,6 +189,7 @@ class _LstmStack:
                 st.bias_part[l] = ptr(bparts[l])
             call("s2g_lstm64_stack_bwd", ctypes.byref(st), ptr(lengths), B, T, stream_ptr())
             if fan is not None:
+                fan.hold(*fused, *bparts, dh)
                 fan.fork_ev[1].record()
                 for l, stream, sc in ((1, fan.b, fan.scratch_b), (0, fan.c, fan.scratch_c)):
                     with ops.on_stream(stream):

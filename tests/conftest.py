@@ -52,12 +52,25 @@ def assert_update_close(new, old, ref_new, tol, what=""):
 NOISE_ONLY = ("model.2.bias", "model.5.bias")
 
 
-def assert_close(a, b, tol, what="", atol=0.0):
-    """Relative L2 check; `atol` (absolute L2 slack per sqrt(numel)) covers tensors that are
-    mathematically zero (e.g. the gradient of a bias that feeds a batch-norm)."""
+def assert_close(a, b, tol, what="", atol=0.0, elem=True):
+    """Two bounds.  (1) Relative L2: |a - b|_2 <= tol |b|_2 (+ `atol` absolute L2 slack per sqrt(numel), for tensors
+    that are mathematically zero, e.g. the gradient of a bias that feeds a batch-norm).  (2) Element by element:
+    |a_i - b_i| <= tol |b_i| + tol rms(b) (+ 5 atol): the norm alone would accept a tensor whose small entries are
+    wrong by 100 % as long as its large entries are right; here an entry may be off by `tol` of its own size plus
+    `tol` of the tensor's root-mean-square entry (sums of thousands of fp32 terms taken in another order differ by
+    rounding that scales with the tensor, not with the entry)."""
     a = torch.as_tensor(a).detach().double().cpu(); b = torch.as_tensor(b).detach().double().cpu()
     assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
     assert torch.isfinite(a).all(), f"{what}: non-finite values"
     err = float((a - b).norm())
     lim = tol * float(b.norm()) + atol * (b.numel() ** 0.5)
     assert err <= lim, f"{what}: L2 error {err:.3e} > {lim:.3e} (rel {err / (float(b.norm()) + 1e-30):.3e}, tol {tol:.1e})"
+    if elem and b.numel():
+        rms = float(b.norm()) / (b.numel() ** 0.5)
+        bound = tol * b.abs() + (tol * rms + 5.0 * atol)       # atol is an rms-level slack: 5 sigma per entry
+        excess = ((a - b).abs() - bound).reshape(-1)
+        worst = int(excess.argmax())
+        assert float(excess[worst]) <= 0.0, (
+            f"{what}: element {worst}: {float(a.reshape(-1)[worst]):.6e} vs {float(b.reshape(-1)[worst]):.6e} "
+            f"(|diff| {float((a - b).abs().reshape(-1)[worst]):.3e} > {float(bound.reshape(-1)[worst]):.3e}; "
+            f"tensor rms {rms:.3e}, tol {tol:.1e})")

@@ -259,12 +259,15 @@ def test_stack_sweeps_match_the_per_layer_sweeps(layers, use_mask):
         assert_close(bp[l], d.view(B, T, G4).sum(1), 1e-4, f"bias sums {l}", atol=1e-5)
 
 
-def test_one_stream_and_overlapped_critic_steps_agree():
+@pytest.mark.parametrize("B,T", [(12, 64), (48, 384)])
+def test_one_stream_and_overlapped_critic_steps_agree(B, T):
     """critic_step with everything on the caller's stream (overlap = False: the fake pass accumulates into the real
     pass's gradients, no side streams) against the default schedule (fake pass and weight-gradient products on side
     streams, two gradient buffers added at the end): same loss, gradients and updated weights to 1e-5, on a ragged
-    batch with dropout masks."""
-    V, B, T = 175, 12, 64
+    batch with dropout masks.  Each schedule runs the FIRST step of a fresh engine (cold split-K scratch: the step
+    allocates while the side streams still read the reverse sweep's outputs; the larger shape makes those
+    buffers big enough that a block freed too early would be handed out again)."""
+    V = 175
     tokens, labels, lengths = common.batch(1710, B, T, vocab=V, min_len=1)
     g = common.gen(1720)
     noise = torch.randint(0, V, (B, 100), generator=g)
