@@ -319,7 +319,7 @@ def main():
 
     import common
     tr = WGANGPTrainer(V, GEN_SEQ_LEN, dev, lr=2e-4, b1=0.5, b2=0.999, lambda_gp=10.0, tau=0.5, hard=False,
-                       n_critic=N_CRITIC, drop_rate=a.drop_rate, comm=comm, seed=42 + rank,   # per-rank noise streams
+                       n_critic=N_CRITIC, drop_rate=a.drop_rate, comm=comm, seed=42,   # the trainer derives per-rank noise streams
                        dtype=a.dtype)
     if os.environ.get("S2G_NO_OVERLAP") == "1":
         tr.D.overlap = False                                      # one stream, launch after launch (debugging aid)
@@ -350,12 +350,18 @@ def main():
     torch.cuda.synchronize()
     prewarm = 0
     with torch.cuda.stream(torch.cuda.Stream(device=dev)):
-        if world == 1:
+        if world > 1:
+            # several ranks: the same FIXED number of untimed steps on every rank (the ranks issue collectives in
+            # lockstep, so none may decide by its own clock when it is warm)
+            for k in range(100):
+                one_step(k)
+            torch.cuda.synchronize()
+            prewarm = 100
+        else:
             # A freshly leased box enqueues slowly for its first tens of seconds (host side: 7 ms per step against
             # 4 ms a minute later, same binary), which makes the step launch-bound.  Untimed blocks of steps run
             # until the host's enqueue time per step stops improving (at least 3 blocks, at most ~12 s); the W
-            # warmup steps and the K timed steps follow unchanged.  Single-process runs only: ranks must stay in
-            # lockstep, and the driver's multi-rank runs follow its one-rank run on the same node.
+            # warmup steps and the K timed steps follow unchanged.
             best, stale, t_pre = float("inf"), 0, time.perf_counter()
             while time.perf_counter() - t_pre < 12.0:
                 t_blk = time.perf_counter()
@@ -374,6 +380,7 @@ def main():
         if comm is not None:
             comm.barrier()
         torch.cuda.synchronize()
+        calls0 = comm.calls if comm is not None else 0
         t0 = time.perf_counter()
         for k in range(a.steps):
             one_step(a.warmup + k)
@@ -463,6 +470,7 @@ def main():
             "ms_per_critic_iteration_est": ms_per_step / (N_CRITIC + 0.3),
             "host_enqueue_ms_per_step": t_host / a.steps * 1e3,
             "prewarm_steps": prewarm,
+            "collectives_per_step": ((comm.calls - calls0) / a.steps if comm is not None else 0),
             "roofline": {"bound": "mfma", "kernel": dom,
                          "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,

@@ -32,10 +32,14 @@ def generator_shapes(vocab: int, seq_len: int, n_classes: int = 2):
 
 class NoComm:
     world = 1
-    split = False          # True: take the multi-rank code paths (all-reduces between the split kernels)
+    rank = 0
+    split = False          # True: take the multi-rank code paths (replicated small layers, all-reduced buckets)
 
     def allreduce(self, t: torch.Tensor) -> None:  # sum over ranks, in place
         return
+
+    def allgather_rows(self, t: torch.Tensor) -> torch.Tensor:
+        return t
 
 
 class GeneratorEngine:
@@ -63,26 +67,33 @@ class GeneratorEngine:
 
     # ------------------------------------------------------------------ forward
     def _bn(self, pre, name, training, update_running, B, F_):
+        """BatchNorm1d(eps=0.8) + LeakyReLU on all B rows of `pre`.  Training: batch statistics + normalise in
+        one launch (with several ranks `pre` holds the GLOBAL batch, so the statistics are exact without an
+        exchange); eval: the running statistics."""
         p = self.params.views
         y = torch.empty_like(pre)
         xhat = torch.empty_like(pre) if training else None
         invstd = torch.empty(F_, device=self.device) if training else None
-        stats = None
-        n_global = float(B * self.comm.world)
-        if training and not self.comm.split:
-            # one process: batch statistics need no all-reduce, statistics + normalise in one launch
+        if training:
             call("s2g_bn_lrelu_fwd_fused", ptr(pre), ptr(p[name + ".weight"]), ptr(p[name + ".bias"]),
                  ptr(self.buffers[name + ".running_mean"]), ptr(self.buffers[name + ".running_var"]), BN_EPS,
                  BN_MOMENTUM, int(update_running), ptr(y), ptr(xhat), ptr(invstd), B, F_, stream_ptr())
             return y, xhat, invstd
-        if training:
-            stats = torch.empty(2 * F_, device=self.device)
-            call("s2g_bn_stats", ptr(pre), ptr(stats), B, F_, stream_ptr())
-            self.comm.allreduce(stats)
-        call("s2g_bn_lrelu_apply", ptr(pre), ptr(stats), n_global, ptr(p[name + ".weight"]), ptr(p[name + ".bias"]),
+        call("s2g_bn_lrelu_apply", ptr(pre), None, float(B), ptr(p[name + ".weight"]), ptr(p[name + ".bias"]),
              ptr(self.buffers[name + ".running_mean"]), ptr(self.buffers[name + ".running_var"]), BN_EPS,
-             BN_MOMENTUM, int(training and update_running), ptr(y), ptr(xhat), ptr(invstd), B, F_, stream_ptr())
+             BN_MOMENTUM, 0, ptr(y), None, None, B, F_, stream_ptr())
         return y, xhat, invstd
+
+    def shard(self, rows: int):
+        """(first row, rows) of this rank's samples within the `rows` the small layers ran on: everything for
+        one process; with several ranks the small layers take the global batch and the output Linear, the
+        sampler and everything behind them this rank's contiguous share of it."""
+        if not self.comm.split:
+            return 0, rows
+        if rows % self.comm.world:
+            raise S2GError("generator: the global batch must divide evenly over the ranks")
+        per = rows // self.comm.world
+        return self.comm.rank * per, per
 
     def forward(self, z: torch.Tensor, labels: torch.Tensor, U: Optional[torch.Tensor], tau: float, hard: bool,
                 training: bool = True, save: bool = True, act: str = "gumbel_softmax",
@@ -90,25 +101,29 @@ class GeneratorEngine:
         """heavy_after: optional callable run between the small layers and the output Linear; a caller
         that runs this forward beside other work makes the current stream wait for an event in it, so
         that the HBM-bound part (183 MB of weights) does not collide with its own heavy kernels.
-        workgroups: CUs the current stream can reach when it is CU-masked (sizes the output layer's grid)."""
+        workgroups: CUs the current stream can reach when it is CU-masked (sizes the output layer's grid).
+        With several ranks z and labels are the GLOBAL batch's (identical on every rank; the small layers run
+        on all of it), while U, out and the returned sample are this rank's share (see shard())."""
         ops._chk(z, name="noise")
         ops._chk(labels, torch.int64, "labels")
-        B = z.shape[0]
-        if z.shape[1] != LATENT or labels.shape[0] != B:
+        Bt = z.shape[0]
+        if z.shape[1] != LATENT or labels.shape[0] != Bt:
             raise S2GError("generator: noise must be [B,100] and labels [B]")
+        lo, B = self.shard(Bt)
         p = self.params.views
         dev = self.device
-        x0 = torch.empty(B, LATENT, device=dev)
-        call("s2g_embed_mul", ptr(z), ptr(labels), ptr(p["label_embedding.weight"]), ptr(x0), B, LATENT,
+        x0 = torch.empty(Bt, LATENT, device=dev)
+        call("s2g_embed_mul", ptr(z), ptr(labels), ptr(p["label_embedding.weight"]), ptr(x0), Bt, LATENT,
              self.n_classes, stream_ptr())
-        a1 = torch.empty(B, 128, device=dev)
+        a1 = torch.empty(Bt, 128, device=dev)
         ops.linear_fwd(x0, p["model.0.weight"], p["model.0.bias"], a1, act=1)
-        pre2 = torch.empty(B, 256, device=dev)
+        pre2 = torch.empty(Bt, 256, device=dev)
         ops.linear_fwd(a1, p["model.2.weight"], p["model.2.bias"], pre2)
-        a2, xhat2, inv2 = self._bn(pre2, "model.3", training, True, B, 256)
-        pre3 = torch.empty(B, 512, device=dev)
+        a2, xhat2, inv2 = self._bn(pre2, "model.3", training, True, Bt, 256)
+        pre3 = torch.empty(Bt, 512, device=dev)
         ops.linear_fwd(a2, p["model.5.weight"], p["model.5.bias"], pre3)
-        a3, xhat3, inv3 = self._bn(pre3, "model.6", training, True, B, 512)
+        a3_all, xhat3, inv3 = self._bn(pre3, "model.6", training, True, Bt, 512)
+        a3 = a3_all[lo:lo + B]                 # this rank's rows (a contiguous view)
         if training:
             self.num_batches_tracked += 1
         logits = torch.empty(B, self.L * self.V, device=dev)
@@ -123,8 +138,9 @@ class GeneratorEngine:
         y, y_soft = ops.gumbel_softmax_fwd(logits.view(B, self.L, self.V), U if mode == 0 else None, tau, mode,
                                            hard, out=out, rng=self.rng)
         if save:
-            self.saved = dict(z=z, labels=labels, x0=x0, a1=a1, a2=a2, xhat2=xhat2, inv2=inv2, a3=a3, xhat3=xhat3,
-                              inv3=inv3, y_soft=y_soft, scale=(1.0 if mode == 2 else 1.0 / tau), B=B)
+            self.saved = dict(z=z, labels=labels, x0=x0, a1=a1, a2=a2, xhat2=xhat2, inv2=inv2, a3=a3, a3_all=a3_all,
+                              xhat3=xhat3, inv3=inv3, y_soft=y_soft, scale=(1.0 if mode == 2 else 1.0 / tau), B=B,
+                              Bt=Bt)
         return y
 
     def hidden(self, z: torch.Tensor, labels: torch.Tensor, training: bool) -> torch.Tensor:
@@ -178,22 +194,9 @@ class GeneratorEngine:
     # ------------------------------------------------------------------ backward
     def _bn_bwd(self, a, da, xhat, inv, name, B, F_):
         g = self.grads.views
-        if not self.comm.split:
-            dpre = torch.empty_like(da)
-            call("s2g_bn_lrelu_bwd_fused", ptr(a), ptr(da), ptr(xhat), ptr(self.params.views[name + ".weight"]),
-                 ptr(inv), ptr(g[name + ".weight"]), ptr(g[name + ".bias"]), ptr(dpre), B, F_, stream_ptr())
-            return dpre
-        sums = torch.empty(2 * F_, device=self.device)
-        call("s2g_bn_lrelu_bwd_stats", ptr(a), ptr(da), ptr(xhat), ptr(sums), B, F_, stream_ptr())
-        self.comm.allreduce(sums)
-        # sums are global already; the flat gradient bucket is SUM-reduced over ranks afterwards,
-        # so each rank contributes 1/world of them
-        share = 1.0 / float(self.comm.world)
-        ops.reduce_slabs(sums, F_, 1, 1, F_, g[name + ".bias"], scale=share)
-        ops.reduce_slabs(sums[F_:], F_, 1, 1, F_, g[name + ".weight"], scale=share)
         dpre = torch.empty_like(da)
-        call("s2g_bn_bwd_apply", ptr(da), ptr(xhat), ptr(sums), float(B * self.comm.world),
-             ptr(self.params.views[name + ".weight"]), ptr(inv), ptr(dpre), B, F_, stream_ptr())
+        call("s2g_bn_lrelu_bwd_fused", ptr(a), ptr(da), ptr(xhat), ptr(self.params.views[name + ".weight"]),
+             ptr(inv), ptr(g[name + ".weight"]), ptr(g[name + ".bias"]), ptr(dpre), B, F_, stream_ptr())
         return dpre
 
     def last_layer_grads(self, dl2: torch.Tensor, a3: torch.Tensor, scratch: ops.Scratch) -> None:
@@ -206,6 +209,11 @@ class GeneratorEngine:
         """Bias gradient of the output Linear alone (its weight gradient is consumed inside the fused update)."""
         ops.colsum(dl2, dl2.shape[0], self.L * self.V, self.L * self.V, self.grads.views["model.8.bias"], scratch)
 
+    def small_layers_replicated(self) -> bool:
+        """True when the small layers run on the global batch on every rank (several ranks): their gradients
+        come out global and identical everywhere, so only the output Linear's bucket is all-reduced."""
+        return bool(self.comm.split)
+
     def last_layer_range(self):
         """[lo, hi) of the output Linear's weight and bias in the flat parameter buffer (adjacent views)."""
         lo = self.params.offsets["model.8.weight"][0]
@@ -213,8 +221,11 @@ class GeneratorEngine:
         return lo, ob + (nb + 3) // 4 * 4
 
     def backward(self, dy: torch.Tensor, last_layer=None) -> None:
-        """Fills self.grads from d loss/d y with this rank's share: summing the buffer over ranks
-        gives the global gradient (BN gamma/beta enter as global/world).
+        """Fills self.grads from d loss/d y (this rank's samples, losses normalised by the GLOBAL batch).
+        One process: the gradient.  Several ranks: the output Linear's entries are this rank's share (summing
+        them over the ranks gives the global gradient); d(a3) of all ranks is gathered and the small layers'
+        backward runs on the global batch, so THEIR entries are the global gradient already, identical on
+        every rank, and must not be summed again (small_layers_replicated()).
 
         last_layer: optional callable(dl2, a3) that takes over the output Linear's gradients (the
         trainer runs them, and that layer's update, on a second stream beside the rest of this
@@ -223,19 +234,21 @@ class GeneratorEngine:
         s = self.saved
         if not s:
             raise S2GError("generator.backward called without a saved forward")
-        B = s["B"]
+        B, Bl = s["Bt"], s["B"]           # rows of the small layers (the global batch with several ranks), of this rank
         p, g, sc, dev = self.params.views, self.grads.views, self.scratch, self.device
         dlogits = ops.gumbel_softmax_bwd(s["y_soft"], dy.contiguous().view_as(s["y_soft"]), s["scale"])
-        dl2 = dlogits.view(B, self.L * self.V)
-        da3 = torch.empty(B, 512, device=dev)
+        dl2 = dlogits.view(Bl, self.L * self.V)
+        da3 = torch.empty(Bl, 512, device=dev)
         ops.linear_bwd_dx(dl2, p["model.8.weight"], da3, sc)
         if last_layer is None:
             self.last_layer_grads(dl2, s["a3"], sc)
         else:
             last_layer(dl2, s["a3"])
+        if B != Bl:
+            da3 = self.comm.allgather_rows(da3)     # [B_global, 512], rank order = row order of the global batch
         # the chain d(a3) -> d(x0) first (every link waits for the one before), then the weight and bias
         # gradients of the three small layers, which hang off it, in ONE launch
-        dpre3 = self._bn_bwd(s["a3"], da3, s["xhat3"], s["inv3"], "model.6", B, 512)
+        dpre3 = self._bn_bwd(s["a3_all"], da3, s["xhat3"], s["inv3"], "model.6", B, 512)
         da2 = torch.empty(B, 256, device=dev)
         ops.linear_bwd_dx(dpre3, p["model.5.weight"], da2, sc)
         dpre2 = self._bn_bwd(s["a2"], da2, s["xhat2"], s["inv2"], "model.3", B, 256)

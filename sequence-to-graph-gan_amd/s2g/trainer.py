@@ -59,9 +59,18 @@ class WGANGPTrainer:
         self.adam_g = tuple(adam_g) if adam_g is not None else (lr, b1, b2, eps)
         self.lambda_gp, self.tau, self.hard, self.n_critic, self.drop_rate = lambda_gp, tau, hard, n_critic, drop_rate
         self.V, self.L = vocab, gen_seq_len
+        rank = getattr(self.comm, "rank", 0)
         if seed is not None:
-            self.G.rng = ops.DeviceRng(seed)      # default: torch.initial_seed() when the engine was built
+            # rank r draws its Gumbel uniforms, alpha and dropout masks from a key of its own (rank 0: `seed` itself)
+            self.G.rng = ops.DeviceRng((int(seed) + rank * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)
         self.rng = self.G.rng           # one stream of draws: z, Gumbel uniforms, alpha, dropout masks
+        # several ranks: z of the GLOBAL batch is drawn identically on every rank (the generator's small layers
+        # run replicated on the global batch), from a key all ranks share: rank 0's, handed round once
+        self.rng_shared = None
+        if self.comm.split:
+            base = int(seed) if seed is not None else torch.initial_seed()
+            self.rng_shared = ops.DeviceRng(self.comm.broadcast_int(base, self.device) ^ 0x6A09E667F3BCC908)
+        self._labels_global: Dict[int, tuple] = {}    # id(local labels) -> (local labels, global labels)
         self.mD_named, self.vD_named = self.D.params.like(), self.D.params.like()   # Adam moments (named views)
         self.mG_named, self.vG_named = self.G.params.like(), self.G.params.like()
         self.mD, self.vD = self.mD_named.flat, self.vD_named.flat
@@ -81,15 +90,37 @@ class WGANGPTrainer:
         self.last: Dict[str, torch.Tensor] = {}
 
     # ------------------------------------------------------------------ updates
-    def _adam(self, eng, m, v, step, lo: int = 0, hi: Optional[int] = None):
-        """Gradient all-reduce + Adam on [lo, hi) of the engine's flat buffers (everything by default)."""
+    def _adam(self, eng, m, v, step, lo: int = 0, hi: Optional[int] = None, reduce: bool = True):
+        """Gradient all-reduce + Adam on [lo, hi) of the engine's flat buffers (everything by default).
+        reduce=False: the gradients are global already (the generator's replicated small layers)."""
         hi = eng.params.total if hi is None else hi
         if hi <= lo:
             return
         g = eng.grads.flat[lo:hi]
-        self.comm.allreduce(g)
+        if reduce:
+            self.comm.allreduce(g)
         lr, b1, b2, eps = self.adam_g if eng is self.G else (self.lr, self.b1, self.b2, self.eps)
         ops.adam(eng.params.flat[lo:hi], g, m[lo:hi], v[lo:hi], lr, b1, b2, eps, step)
+
+    def _gen_inputs(self, z: Optional[torch.Tensor], labels: torch.Tensor, B: int):
+        """(noise, labels) as GeneratorEngine.forward takes them.  One process: this batch's z (drawn here when
+        None) and labels.  Several ranks: the GLOBAL batch's -- z drawn from the key all ranks share (an
+        injected shard is gathered instead: tests), labels gathered once per labels tensor and remembered."""
+        dev = self.device
+        if not self.comm.split:
+            if z is None:
+                z = ops.rng_fill(torch.empty(B, LATENT, device=dev), 1, self.rng)
+            return z, labels
+        hit = self._labels_global.get(id(labels))
+        if hit is None or hit[0] is not labels:
+            while len(self._labels_global) >= 256:
+                self._labels_global.pop(next(iter(self._labels_global)))
+            hit = self._labels_global[id(labels)] = (labels, self.comm.allgather_rows(labels))
+        if z is None:
+            z = ops.rng_fill(torch.empty(B * self.comm.world, LATENT, device=dev), 1, self.rng_shared)
+        else:
+            z = self.comm.allgather_rows(z)
+        return z, hit[1]
 
     def _fake_buf(self, which: int, B: int) -> torch.Tensor:
         # persistent output buffers: stable pointers let the grouped-GEMM problem table be reused
@@ -154,9 +185,9 @@ class WGANGPTrainer:
         desc = None
         pre = self._prefetched
         self._prefetched = None
-        if pre is not None and pre["labels"] is labels and (z is None or z is pre["z"]):
+        if pre is not None and pre["labels"] is labels and (z is None or z is pre["z_in"]):
             self._join_generator()
-            z, fake = pre["z"], self._fake_buf(self._fake_cur, B)
+            zg, lg, fake = pre["z"], pre["labels_gen"], self._fake_buf(self._fake_cur, B)
             torch.cuda.current_stream().wait_event(pre["done"])
             if alpha is None:
                 alpha = pre.get("alpha")
@@ -169,8 +200,7 @@ class WGANGPTrainer:
         else:
             if pre is not None:
                 torch.cuda.current_stream().wait_event(pre["done"])     # keep the generator's buffer updates ordered
-            if z is None:
-                z = ops.rng_fill(torch.empty(B, LATENT, device=dev), 1, self.rng)
+            zg, lg = self._gen_inputs(z, labels, B)      # what the generator takes (the global batch's with several ranks)
             # this batch's own draws and sequence descriptors BEFORE the generator forward: after a generator
             # update that forward waits (just before its last layer) for the output layer's update on the side
             # stream, and whatever is enqueued ahead of the wait runs meanwhile instead of after it
@@ -183,7 +213,7 @@ class WGANGPTrainer:
                 self._desc[self._desc_cur] = torch.zeros(4 * B, 8, dtype=torch.int32, device=dev)
             desc = self._desc[self._desc_cur]
             batch_desc(lengths, alpha.reshape(-1), B, T, self.L, mask is not None, desc)
-            fake = self.G.forward(z, labels, U, self.tau, self.hard, training=True, save=False,
+            fake = self.G.forward(zg, lg, U, self.tau, self.hard, training=True, save=False,
                                   out=self._fake_buf(self._fake_cur, B))    # .detach(): no graph is kept
             self._join_generator(waited=True)     # the forward waited for a pending output-layer update
         if alpha is None:
@@ -195,13 +225,13 @@ class WGANGPTrainer:
         # (with several ranks the prefetched forwards issue their BatchNorm all-reduces from the second stream;
         # every rank runs the same host code, so all ranks issue their collectives in the same order)
         if next_batch is not None and self.D.overlap:
-            nxt = dict(labels=next_batch["labels"], z=next_batch.get("z"), done=torch.cuda.Event())
+            nxt = dict(labels=next_batch["labels"], z_in=next_batch.get("z"), done=torch.cuda.Event())
             other = self._fake_buf(self._fake_cur ^ 1, B)
 
             def prefetch(heavy_after=None):
-                if nxt["z"] is None:        # drawn on the prefetch stream: nothing of it sits on the caller's
-                    nxt["z"] = ops.rng_fill(torch.empty(B, LATENT, device=dev), 1, self.rng)
-                self.G.forward(nxt["z"], nxt["labels"], next_batch.get("U"), self.tau, self.hard, training=True,
+                # (z drawn on the prefetch stream: nothing of it sits on the caller's)
+                nxt["z"], nxt["labels_gen"] = self._gen_inputs(nxt["z_in"], nxt["labels"], B)
+                self.G.forward(nxt["z"], nxt["labels_gen"], next_batch.get("U"), self.tau, self.hard, training=True,
                                save=False, out=other, heavy_after=heavy_after, workgroups=self.D.cu_masked)
                 nxt["done"].record()
 
@@ -222,10 +252,10 @@ class WGANGPTrainer:
                     nxt["desc"] = self._desc[self._desc_cur]
                     nxt["desc_key"] = (B, next_batch["T"], self.L, use_mask)
         elif gen_next is not None and self.D.overlap:
-            gp = dict(z=z, labels=labels, U=gen_next.get("U"), done=torch.cuda.Event())
+            gp = dict(z=zg, labels=labels, U=gen_next.get("U"), done=torch.cuda.Event())
 
             def prefetch(heavy_after=None):
-                gp["fake"] = self.G.forward(z, labels, gp["U"], self.tau, self.hard, training=True, save=True,
+                gp["fake"] = self.G.forward(zg, lg, gp["U"], self.tau, self.hard, training=True, save=True,
                                             heavy_after=heavy_after, workgroups=self.D.cu_masked)
                 gp["done"].record()
 
@@ -251,7 +281,8 @@ class WGANGPTrainer:
             else:
                 self._adam(self.D, self.mD, self.vD, self.tD)
                 self.D.repack()
-        self.last = dict(z=z, labels=labels, d_parts=losses, pen=pen, n_global=n_global, wsum=wsum)
+        # z / labels_gen: the generator's inputs of this batch (the global batch's with several ranks)
+        self.last = dict(z=zg, labels=labels, labels_gen=lg, d_parts=losses, pen=pen, n_global=n_global, wsum=wsum)
         return losses, pen
 
     def d_loss(self) -> torch.Tensor:
@@ -270,13 +301,20 @@ class WGANGPTrainer:
         generator forward waits for it just before that layer (full_step uses this).
         keep_grads: False lets the output Linear's weight gradient stay in registers (one process: its
         product and its Adam step are one kernel); G.grads then holds every gradient but that one."""
-        labels = self.last["labels"] if labels is None else labels
-        z = self.last["z"] if z is None else z
+        if labels is None and z is None:
+            labels, z, lg = self.last["labels"], self.last["z"], self.last["labels_gen"]
+        else:
+            labels = self.last["labels"] if labels is None else labels
+            if z is None and not self.comm.split:
+                z = self.last["z"]
+            elif z is None:
+                raise S2GError("generator_step: with several ranks pass z together with labels (or neither)")
+            z, lg = self._gen_inputs(z, labels, labels.shape[0])
         wsum = self.last["wsum"] if wsum is None else wsum
         if self._prefetched is not None:          # a prefetched forward nobody consumed: stay ordered behind it
             torch.cuda.current_stream().wait_event(self._prefetched["done"])
             self._prefetched = None
-        B = z.shape[0]
+        B = labels.shape[0]
         n_global = B * self.comm.world
         gp, self._gen_prefetched = self._gen_prefetched, None
         if gp is not None:
@@ -286,12 +324,15 @@ class WGANGPTrainer:
             if mask is None:
                 mask = gp.get("mask")
         else:
-            fake = self.G.forward(z, labels, U, self.tau, self.hard, training=True, save=True)
+            fake = self.G.forward(z, lg, U, self.tau, self.hard, training=True, save=True)
         if mask is None and self.drop_rate > 0.0:
             mask = dropout_mask(B * self.L, self.drop_rate, self.device, self.rng)
         losses, dfake = critic_forward_backward_fake(self.D, fake, labels, n_global, 1.0 / wsum, mask, CLASS_W)
         side = self.D.side() if (update and self.D.overlap) else None
         lo, hi = self.G.last_layer_range()
+        # several ranks: the small layers' gradients are global and identical on every rank already (computed on the
+        # gathered global batch); only the output Linear's bucket is all-reduced
+        small_reduce = not self.G.small_layers_replicated()
         # one process and a batch the kernel takes: the output Linear's weight gradient and its Adam step in ONE
         # pass over W, m, v (6 passes over 184 MB instead of 10); with several ranks the gradient must be
         # all-reduced first, so the product and the flat Adam stay separate
@@ -315,8 +356,8 @@ class WGANGPTrainer:
             if update:
                 self.tG += 1
                 self.G.backward(dfake, last_layer=last_layer_update)
-                self._adam(self.G, self.mG, self.vG, self.tG, 0, lo)
-                self._adam(self.G, self.mG, self.vG, self.tG, hi, self.G.params.total)
+                self._adam(self.G, self.mG, self.vG, self.tG, 0, lo, reduce=small_reduce)
+                self._adam(self.G, self.mG, self.vG, self.tG, hi, self.G.params.total, reduce=small_reduce)
             else:
                 self.G.backward(dfake)
         else:
@@ -339,8 +380,8 @@ class WGANGPTrainer:
                     done.record()
 
             self.G.backward(dfake, last_layer=last_layer)
-            self._adam(self.G, self.mG, self.vG, self.tG, 0, lo)
-            self._adam(self.G, self.mG, self.vG, self.tG, hi, self.G.params.total)
+            self._adam(self.G, self.mG, self.vG, self.tG, 0, lo, reduce=small_reduce)
+            self._adam(self.G, self.mG, self.vG, self.tG, hi, self.G.params.total, reduce=small_reduce)
             self.G.last_layer_ready = done
             self._g_pending = (done, keep)
             if not defer_join:

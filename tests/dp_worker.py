@@ -15,16 +15,19 @@ import torch  # noqa: E402
 import common  # noqa: E402
 
 B, T, TF, V = 16, 32, 24, 175
-DEV = "cuda:0"        # every rank on GPU 0: gloo moves the data, the kernels are the product's
+# S2G_DP_BACKEND=gloo (default): every rank on GPU 0, gloo moves the data, the kernels are the product's;
+# nccl: rank r on GPU LOCAL_RANK, RCCL moves the data.  S2G_DP_FORCE_SPLIT=1: the multi-rank code path even for one rank.
+BACKEND = os.environ.get("S2G_DP_BACKEND", "gloo")
+DEV = "cuda:0" if BACKEND == "gloo" else "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0"))
 
 
 def main():
     from s2g.parallel import global_wsum, init_from_env, shard
     from s2g.trainer import WGANGPTrainer
-    comm, rank, _, world = init_from_env("gloo")
+    comm, rank, _, world = init_from_env(BACKEND, force_split=os.environ.get("S2G_DP_FORCE_SPLIT") == "1")
     lo, hi = shard(B, rank, world)
     n = hi - lo
-    torch.cuda.set_device(0)
+    torch.cuda.set_device(torch.device(DEV))
     tr = WGANGPTrainer(V, TF, DEV, drop_rate=0.3, comm=comm)
     tr.G.load(common.generator_params(1001, V, TF))
     tr.D.load(common.critic_params(1002, scale=1.5))

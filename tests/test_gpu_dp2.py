@@ -23,9 +23,9 @@ def _free_port():
     return p
 
 
-def _spawn(rank, world, port, out):
+def _spawn(rank, world, port, out, **extra):
     env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-               MASTER_PORT=str(port), OUT=out, PYTHONFAULTHANDLER="1")
+               MASTER_PORT=str(port), OUT=out, PYTHONFAULTHANDLER="1", **extra)
     return subprocess.Popen([sys.executable, "-u", os.path.join(HERE, "dp_worker.py")], env=env,
                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
 
