@@ -55,8 +55,9 @@ class DistComm:
             return t.clone()
         self.calls += 1
         out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        if t.is_cuda and dist.get_backend(self.group) == "gloo":
-            torch.cuda.synchronize()
+        if dist.get_backend(self.group) == "gloo":
+            if t.is_cuda:
+                torch.cuda.synchronize()
             dist.all_gather(list(out.chunk(self.world, 0)), t, group=self.group)
         else:
             dist.all_gather_into_tensor(out, t, group=self.group)

@@ -1,6 +1,7 @@
 """Data-parallel conventions of s2g/parallel.py rehearsed with 2 CPU processes over gloo: each rank
 takes a contiguous shard of the batch, normalises its loss by the GLOBAL batch size and the GLOBAL
-class-weight sum, all-reduces per-feature BatchNorm sums, and SUM-all-reduces gradients; the
+class-weight sum and SUM-all-reduces gradients; the generator's BatchNorm layers run replicated on the
+global batch (every rank knows all inputs), their backward on the all-gathered upstream gradient; the
 result must equal the single-process step on the whole batch (oracle arithmetic, float64)."""
 import os
 import socket
@@ -22,14 +23,18 @@ def _free_port():
     return p
 
 
-def _sync_bn_forward(x, gamma, beta, comm, n_global, eps=0.8):
-    """what GeneratorEngine._bn does: local sums -> all-reduce -> normalise."""
-    stats = torch.cat([x.sum(0), (x * x).sum(0)])
-    comm.allreduce(stats)
-    Fdim = x.shape[1]
-    mean = stats[:Fdim] / n_global
-    var = stats[Fdim:] / n_global - mean * mean
-    return (x - mean) / torch.sqrt(var + eps) * gamma + beta
+def _replicated_bn(x_global, gamma, beta, dy_local, comm, eps=0.8):
+    """what GeneratorEngine does with several ranks: BatchNorm on the GLOBAL batch on every rank (exact
+    statistics, no exchange), this rank's rows go on to the sharded output layer; backward: the ranks'
+    upstream gradient rows are gathered in rank order and the layer's backward runs on the global batch.
+    Returns (y of the global batch, dx of the global batch, dgamma, dbeta)."""
+    x = x_global.detach().clone().requires_grad_(True)
+    g, b = gamma.detach().clone().requires_grad_(True), beta.detach().clone().requires_grad_(True)
+    mean, var = x.mean(0), x.var(0, unbiased=False)
+    y = (x - mean) / torch.sqrt(var + eps) * g + b
+    dy = comm.allgather_rows(dy_local)
+    dx, dg, db = torch.autograd.grad(y, [x, g, b], dy)
+    return y.detach(), dx, dg, db
 
 
 def _dp_critic_loss(O, p, real, lengths, fake, labels, alpha, lam, n_global, wsum):
@@ -76,21 +81,27 @@ def _worker(rank, port, ret):
     lt = loss.detach().reshape(1).clone()
     comm.allreduce(lt)
 
-    # SyncBN
+    # BatchNorm replicated on the global batch; every rank contributes its rows of the upstream gradient
     x = torch.randn((B, 5), generator=common.gen(94), dtype=dt)
     gamma, beta = torch.rand(5, generator=g, dtype=dt) + 0.5, torch.rand(5, generator=g, dtype=dt)
-    y_local = _sync_bn_forward(x[lo:hi], gamma, beta, comm, float(B))
+    dy = torch.randn((B, 5), generator=common.gen(95), dtype=dt)
+    y_rep, dx_rep, dg_rep, db_rep = _replicated_bn(x, gamma, beta, dy[lo:hi], comm)
+    assert comm.calls == 4          # world-size gather at set-up aside: wsum, gradient bucket, loss, d(y) gather
 
     if rank == 0:
         p1 = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
         full, _ = O.critic_loss(p1, real, lengths, fake, labels, alpha, 10.0)
         gfull = torch.autograd.grad(full, [p1[n] for n in names])
         ref = torch.cat([x.reshape(-1) for x in gfull])
-        mean, var = x.mean(0), x.var(0, unbiased=False)
-        y_ref = ((x - mean) / torch.sqrt(var + 0.8) * gamma + beta)[lo:hi]
+        xr = x.clone().requires_grad_(True)
+        gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        mean, var = xr.mean(0), xr.var(0, unbiased=False)
+        y_ref = (xr - mean) / torch.sqrt(var + 0.8) * gr + br
+        dx_ref, dg_ref, db_ref = torch.autograd.grad(y_ref, [xr, gr, br], dy)
         ret["grad_err"] = float((flat - ref).norm() / ref.norm())
         ret["loss_err"] = abs(float(lt[0]) - float(full))
-        ret["bn_err"] = float((y_local - y_ref).abs().max())
+        ret["bn_err"] = max(float((y_rep - y_ref.detach()).abs().max()), float((dx_rep - dx_ref).abs().max()),
+                            float((dg_rep - dg_ref).abs().max()), float((db_rep - db_ref).abs().max()))
     comm.barrier()
     torch.distributed.destroy_process_group()
 
