@@ -413,9 +413,13 @@ int s2g_embed_grad_labels(const long long* labels, const int* lengths, int T, in
 int s2g_attnpool_fwd(float* pre, const float* out, const float* wc, const float* wl, const float* bl, int nseq, int T,
                      int Tp, float* weights, float* pooled, float* dval, void* stream);
 /* its autograd for dD [nseq]: a_dpre (tanh(pre) on entry) <- d(pre); dout [rows, 64] = the direct part of d(out);
- * dwc_part [nseq, 64] = every sequence's share of d(context_vector.weight). */
+ * dwc_part [nseq, 64] = every sequence's share of d(context_vector.weight).
+ * dpooled [nseq, 64] (or NULL): the gradient of the pooled vector itself, used instead of dD[n] * wl (Attention.forward
+ * returns the pooled vector, wgan.py:88-89; dD and wl may then be NULL); dweights [nseq, T] (or NULL): a gradient
+ * on the attention weights, its second return value. */
 int s2g_attnpool_bwd(float* a_dpre, const float* out, const float* wc, const float* wl, const float* weights,
-                     const float* dD, int nseq, int T, int Tp, float* dout, float* dwc_part, void* stream);
+                     const float* dD, int nseq, int T, int Tp, float* dout, float* dwc_part, const float* dpooled,
+                     const float* dweights, void* stream);
 /* d_loss = -(mean(D_real) - mean(D_fake)) (wgan.py:145-147) for dval = [real B | fake B], and its derivative dD */
 int s2g_wasserstein_loss(const float* dval, int B, float* dD, float* loss, void* stream);
 /* p <- clamp(p, -clip, clip) (wgan.py:155-158) */

@@ -783,18 +783,23 @@ extern "C" __global__ __launch_bounds__(64 * AP_NW) void s2g_k_attnpool_fwd(floa
 
 // backward of the pooling for d(loss)/d(D_n) = dD[n]: d(out) (direct part: weights_t * dpooled), dpre =
 // ds_t * wc * (1 - a^2) written over a, and this sequence's share of d(wc); d(wl), d(bl) follow from pooled.
+// dpooled [nseq, 64] (optional): the upstream gradient of the pooled vector itself, instead of dD[n] * wl (the
+// module-level Attention.forward returns the pooled vector); dweights [nseq, T] (optional): an upstream gradient
+// on the attention weights (its second return value), added to what flows back through the pooled vector.
 extern "C" __global__ __launch_bounds__(64 * AP_NW) void s2g_k_attnpool_bwd(float* __restrict__ a_dpre, const float* __restrict__ out,
                                                                      const float* __restrict__ wc,
                                                                      const float* __restrict__ wl,
                                                                      const float* __restrict__ weights,
                                                                      const float* __restrict__ dD, int T, int Tp,
-                                                                     float* __restrict__ dout, float* __restrict__ dwc_part) {
+                                                                     float* __restrict__ dout, float* __restrict__ dwc_part,
+                                                                     const float* __restrict__ dpooled,
+                                                                     const float* __restrict__ dweights) {
   extern __shared__ float dw[];             // [Tp] d(weights), then d(scores)
   __shared__ float red[AP_NW][X_H];
   __shared__ float dot_s;
   const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const size_t r0 = (size_t)n * T;
-  const float dp = dD[n] * wl[lane];                       // d(pooled)
+  const float dp = dpooled ? dpooled[(size_t)n * X_H + lane] : dD[n] * wl[lane];      // d(pooled)
   for (int tb = wave; tb < Tp; tb += 8 * AP_NW) {
     float ov[8];
 #pragma unroll
@@ -806,7 +811,7 @@ extern "C" __global__ __launch_bounds__(64 * AP_NW) void s2g_k_attnpool_bwd(floa
         float s = dp * ov[j];
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
-        if (lane == 0) dw[t] = s;
+        if (lane == 0) dw[t] = dweights ? s + dweights[(size_t)n * T + t] : s;
       }
     }
   }

@@ -659,12 +659,13 @@ int s2g_attnpool_fwd(float* pre, const float* out, const float* wc, const float*
   return LAUNCH_OK();
 }
 int s2g_attnpool_bwd(float* a_dpre, const float* out, const float* wc, const float* wl, const float* weights,
-                     const float* dD, int nseq, int T, int Tp, float* dout, float* dwc_part, void* stream) {
-  if (!a_dpre || !out || !wc || !wl || !weights || !dD || !dout || !dwc_part || nseq <= 0 || T <= 0 || Tp <= 0 ||
-      Tp > T || Tp > 12288)
+                     const float* dD, int nseq, int T, int Tp, float* dout, float* dwc_part, const float* dpooled,
+                     const float* dweights, void* stream) {
+  if (!a_dpre || !out || !wc || !weights || !dout || !dwc_part || nseq <= 0 || T <= 0 || Tp <= 0 || Tp > T || Tp > 12288)
     return -1;
+  if (!dpooled && (!dD || !wl)) return -1;               // the upstream gradient: of the pooled vector, or of D through wl
   hipLaunchKernelGGL(s2g_k_attnpool_bwd, dim3(nseq), dim3(64 * AP_NW), (size_t)Tp * sizeof(float), ST(stream), a_dpre, out, wc,
-                     wl, weights, dD, T, Tp, dout, dwc_part);
+                     wl, weights, dD, T, Tp, dout, dwc_part, dpooled, dweights);
   return LAUNCH_OK();
 }
 int s2g_wasserstein_loss(const float* dval, int B, float* dD, float* loss, void* stream) {

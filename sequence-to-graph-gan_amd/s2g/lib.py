@@ -125,7 +125,7 @@ SIGNATURES = {
     "s2g_bucket_rows_by_token": [P, P, I, L, I, P, I, I, P, P, P],
     "s2g_bucket_rows_by_label": [P, I, I, P, I, P, P],
     "s2g_attnpool_fwd": [P, P, P, P, P, I, I, I, P, P, P, P],
-    "s2g_attnpool_bwd": [P, P, P, P, P, P, I, I, I, P, P, P],
+    "s2g_attnpool_bwd": [P, P, P, P, P, P, I, I, I, P, P, P, P, P],
     "s2g_wasserstein_loss": [P, I, P, P, P],
     "s2g_clamp": [P, L, F, P],
     "s2g_mul_inplace": [P, P, L, P],

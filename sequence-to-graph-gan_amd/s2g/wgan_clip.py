@@ -312,16 +312,19 @@ class ClipCriticEngine:
         return dval, state
 
     def backward(self, st, dD: torch.Tensor, accumulate: bool, grads=None, scratch=None,
-                 fan: Optional[_Fan] = None) -> None:
+                 fan: Optional[_Fan] = None, want_dseq: bool = False) -> Optional[torch.Tensor]:
         """Adds (or writes, accumulate=False) the parameter gradients of sum_n dD[n] * D_n into self.grads
         (or `grads`, with `scratch` for the split-K slabs: a pass that runs beside another needs both of its own).
-        fan: streams for the weight-gradient products off the chain of sweeps; joined before this returns."""
+        fan: streams for the weight-gradient products off the chain of sweeps; joined before this returns.
+        want_dseq (relaxed input only): also returns the gradient with respect to the input [B, T, V]
+        (through the matmul branch of RelaxedEmbedding, wgan.py:45)."""
         p, g, dev, sc = self.params.views, (grads or self.grads).views, self.device, scratch or self.scratch
         B, T, Tp, rows = st["B"], st["T"], st["Tp"], st["B"] * st["T"]
         dout = torch.empty(rows, HID, device=dev)
         dwc = torch.empty(B, HID, device=dev)
         call("s2g_attnpool_bwd", ptr(st["a"]), ptr(st["out"]), ptr(p["attention.context_vector.weight"]),
-             ptr(p["linear.weight"]), ptr(st["weights"]), ptr(dD), B, T, Tp, ptr(dout), ptr(dwc), stream_ptr())
+             ptr(p["linear.weight"]), ptr(st["weights"]), ptr(dD), B, T, Tp, ptr(dout), ptr(dwc), None, None,
+             stream_ptr())
         dpre = st["a"]
 
         def head_grads(sc_):
@@ -367,8 +370,13 @@ class ClipCriticEngine:
                 fan.join()
             return
         dx = self.stack.backward(dout, st["lstm"], B, T, st["lengths"], g, sc, accumulate, fan)
+        dseq = None
         if st["soft"]:
             _tn(ptr(st["seq"]), self.V, self.V, ptr(dx), 2 * EMB, EMB, rows, ge, sc, accumulate)
+            if want_dseq:       # d(seq) = d(x)[:, :32] E^T
+                dseq = torch.empty(B, T, self.V, device=dev)
+                ops.gemm_raw(ptr(dx), 2 * EMB, 1, ptr(p["sequence_embedding.embed_layer.weight"]), 1, EMB, ptr(dseq),
+                             self.V, rows, self.V, EMB)
         else:
             lens = st["lengths"]
             if lens is None:
@@ -381,6 +389,7 @@ class ClipCriticEngine:
              ptr(g["label_embedding.weight"]), int(accumulate), ptr(part), stream_ptr())
         if fan is not None:
             fan.join()
+        return dseq
 
     def dropout_masks(self, rows: int):
         if self.dropout <= 0.0:

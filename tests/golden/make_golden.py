@@ -524,6 +524,138 @@ def g12_wgan_clip(ref):
     save("g12_wgan_clip.pt", out)
 
 
+def g14_wgan_clip_full_size(ref):
+    """One critic update of the reference's CWGAN.train_step (wgan.py:174-198) at the size BASELINE names for the
+    weight-clipping variant: B = 128, L = 1024, V = 175, ragged lengths (the longest = 1024), no dropout (the
+    masks of nn.LSTM's inter-layer dropout cannot be captured).  Records d_loss, every critic gradient of the
+    update and the parameters after the clamped Adam step."""
+    sys.modules.setdefault("seaborn", types.ModuleType("seaborn"))
+    import wgan as W                                  # /root/reference/wgan.py
+    assert W.__file__.startswith("/root/reference")
+    V, B, T = 175, 128, 1024
+    pd, pg = common.wgan_clip_params(1801, V)
+    opt = argparse.Namespace(lr=2e-4, beta1=0.5, beta2=0.999, clip_value=0.1, n_critic=5)
+    G = W.Generator(V, 2, 3, softmax="gumbel_softmax")
+    D = W.Discriminator(V, 2, 2, dropout=0.0, use_gpu=False)
+    G.load_state_dict(pg); D.load_state_dict(pd)
+    model = W.CWGAN(G, D, opt)
+    snaps = []
+    model.d_optimizer.register_step_pre_hook(
+        lambda o, a, k: snaps.append({n: q.grad.detach().clone() for n, q in D.named_parameters()}))
+    tokens, labels, lengths = common.batch(1810, B, T, vocab=V, min_len=64)
+    g = common.gen(1820)
+    real_randint = torch.randint
+    noise = real_randint(0, V, (B, 100), generator=g)
+    U = torch.rand((B, 100, V), generator=g)
+    qU = Queue(); qU.push(U)
+    torch.randint = lambda *a, **k: noise.clone()             # wgan.py:183
+    import time
+    t0 = time.perf_counter()
+    try:
+        import io
+        with injected(ref, qU, Queue(), Queue()), contextlib.redirect_stderr(io.StringIO()):
+            d_loss, _ = model.train_step(ListLoader([(tokens, labels, lengths)]), 0.5, False)
+    finally:
+        torch.randint = real_randint
+    out = {"d_loss": torch.tensor(d_loss, dtype=torch.float64), "seconds": torch.tensor(time.perf_counter() - t0)}
+    for n, v in snaps[0].items():
+        out[f"grad.{n}"] = v
+    for n, v in D.state_dict().items():
+        out[f"D.{n}"] = v.clone()
+    print("g14: d_loss", float(out["d_loss"]), "seconds", float(out["seconds"]))
+    save("g14_wgan_clip_full_size.pt", out)
+
+
+def g15_wgan_modules(ref):
+    """The module surface of the reference's wgan.py beyond the critic update: RelaxedEmbedding.forward (:36-45,
+    both branches, with gradients), Attention.forward (:82-89: pooled vector and weights, with gradients for an
+    upstream on both), Discriminator.forward (:106-122) with gradients with respect to every parameter and to
+    a relaxed input, and CWGAN.train (:230-246) with tau annealing over one-batch loaders (i = 0 only, so the
+    broken generator branch is never entered)."""
+    sys.modules.setdefault("seaborn", types.ModuleType("seaborn"))
+    import wgan as W
+    assert W.__file__.startswith("/root/reference")
+    V, B, T = 175, 5, 24
+    pd, pg = common.wgan_clip_params(1901, V)
+    g = common.gen(1902)
+    out = {}
+    # RelaxedEmbedding
+    emb = W.RelaxedEmbedding(V, 32)
+    emb.device = torch.device("cpu")
+    emb.embed_layer = torch.nn.Embedding(V, 32)
+    with torch.no_grad():
+        emb.embed_layer.weight.copy_(pd["sequence_embedding.embed_layer.weight"])
+    tok = torch.randint(0, V, (B, T), generator=g)
+    soft = torch.softmax(torch.randn((B, T, V), generator=g), -1).requires_grad_(True)
+    dy = torch.randn((B, T, 32), generator=g)
+    y_tok = emb(tok)
+    (gw_tok,) = torch.autograd.grad(y_tok, [emb.embed_layer.weight], dy)
+    y_soft = emb(soft)
+    gw_soft, gx_soft = torch.autograd.grad(y_soft, [emb.embed_layer.weight, soft], dy)
+    out.update({"emb.tok": tok, "emb.soft": soft.detach().clone(), "emb.dy": dy, "emb.y_tok": y_tok.detach().clone(),
+                "emb.y_soft": y_soft.detach().clone(), "emb.dW_tok": gw_tok, "emb.dW_soft": gw_soft, "emb.dx_soft": gx_soft})
+    # Attention
+    att = W.Attention(64)
+    with torch.no_grad():
+        att.attn.weight.copy_(pd["attention.attn.weight"]); att.attn.bias.copy_(pd["attention.attn.bias"])
+        att.context_vector.weight.copy_(pd["attention.context_vector.weight"])
+    hidden = torch.randn((B, T, 64), generator=g).requires_grad_(True)
+    lo = torch.randn((B, T, 64), generator=g).requires_grad_(True)
+    d_pool, d_w = torch.randn((B, 64), generator=g), torch.randn((B, T), generator=g)
+    pooled, weights = att(hidden, lo)
+    grads = torch.autograd.grad([pooled, weights], [hidden, lo, att.attn.weight, att.attn.bias, att.context_vector.weight],
+                                [d_pool, d_w])
+    out.update({"att.hidden": hidden.detach().clone(), "att.lstm_outputs": lo.detach().clone(), "att.d_pooled": d_pool,
+                "att.d_weights": d_w, "att.pooled": pooled.detach().clone(), "att.weights": weights.detach().clone()})
+    for n, gv in zip(("d_hidden", "d_lstm_outputs", "d_attn_w", "d_attn_b", "d_context"), grads):
+        out[f"att.{n}"] = gv.clone()
+    # Discriminator.forward, differentiable: tokens and a relaxed input
+    D = W.Discriminator(V, 2, 2, dropout=0.0, use_gpu=False)
+    D.load_state_dict(pd)
+    tokens, labels, lengths = common.batch(1910, B, T, vocab=V, min_len=3)
+    dval = torch.randn((B, 1), generator=g)
+    names = [n for n, _ in D.named_parameters()]
+    val = D(tokens, labels, lengths)
+    gt = torch.autograd.grad(val, [q for _, q in D.named_parameters()], dval, allow_unused=True)
+    out.update({"D.tokens": tokens, "D.labels": labels, "D.lengths": lengths, "D.dval": dval, "D.val_tok": val.detach().clone()})
+    for n, gv in zip(names, gt):
+        out[f"D.grad_tok.{n}"] = torch.zeros_like(dict(D.named_parameters())[n]) if gv is None else gv.clone()
+    x = torch.softmax(torch.randn((B, T, V), generator=g) * 3.0, -1).requires_grad_(True)
+    full = torch.full((B,), T, dtype=torch.long)
+    val2 = D(x, labels, full)
+    gs = torch.autograd.grad(val2, [x] + [q for _, q in D.named_parameters()], dval, allow_unused=True)
+    out.update({"D.soft": x.detach().clone(), "D.val_soft": val2.detach().clone(), "D.dx_soft": gs[0].clone()})
+    for n, gv in zip(names, gs[1:]):
+        out[f"D.grad_soft.{n}"] = torch.zeros_like(dict(D.named_parameters())[n]) if gv is None else gv.clone()
+    # CWGAN.train: three epochs over a one-batch loader with tau annealing every epoch
+    opt = argparse.Namespace(lr=2e-4, beta1=0.5, beta2=0.999, clip_value=0.1, n_critic=5)
+    G2 = W.Generator(V, 2, 3, softmax="gumbel_softmax")
+    D2 = W.Discriminator(V, 2, 2, dropout=0.0, use_gpu=False)
+    G2.load_state_dict(pg); D2.load_state_dict(pd)
+    model = W.CWGAN(G2, D2, opt)
+    noises = [torch.randint(0, V, (B, 100), generator=g) for _ in range(3)]
+    Us = [torch.rand((B, 100, V), generator=g) for _ in range(3)]
+    qU, qN = Queue(), Queue()
+    qU.push(*Us); qN.push(*noises)
+    real_randint = torch.randint
+    torch.randint = qN.pop
+    import io
+    buf = io.StringIO()
+    try:
+        with injected(ref, qU, Queue(), Queue()), contextlib.redirect_stderr(io.StringIO()), contextlib.redirect_stdout(buf):
+            model.train(ListLoader([(tokens, labels, lengths)]), epochs=3, tau=0.5, hard=False, anneal_tau=True, anneal_interval=1)
+    finally:
+        torch.randint = real_randint
+    out["train.noise"] = torch.stack(noises); out["train.U"] = torch.stack(Us)
+    out["train.d_losses"] = torch.tensor(model.losses["d_loss"], dtype=torch.float64)
+    out["train.g_losses"] = torch.tensor(model.losses["g_loss"], dtype=torch.float64)
+    out["train.printed"] = buf.getvalue()
+    for n, v in D2.state_dict().items():
+        out[f"train.D.{n}"] = v.clone()
+    print("g15: train printed:\n" + buf.getvalue())
+    save("g15_wgan_modules.pt", out)
+
+
 def g13_graph_encoder(ref):
     """GraphEncoder.encode (graph_encoder.py:57-133) on the sequences of common.graph_sequences with one encoder
     (its vocabulary grows across calls), plus the float64 centralities from the same networkx calls the reference
@@ -589,9 +721,9 @@ def main():
     a = ap.parse_args()
     torch.manual_seed(0)
     ref = import_reference()
-    todo = [g1_sampler, g2_generator, g3_critic, g4_gp, g5_ce, g6_adam, g7_full_step, g10_generate_fake_data, g11_attention, g12_wgan_clip, g13_graph_encoder]
+    todo = [g1_sampler, g2_generator, g3_critic, g4_gp, g5_ce, g6_adam, g7_full_step, g10_generate_fake_data, g11_attention, g12_wgan_clip, g13_graph_encoder, g15_wgan_modules]
     if a.full:
-        todo += [g8_full_size, g9_full_step_full_size]
+        todo += [g8_full_size, g9_full_step_full_size, g14_wgan_clip_full_size]
     for fn in todo:
         if a.only and a.only not in fn.__name__:
             continue

@@ -289,3 +289,124 @@ def test_one_stream_and_overlapped_critic_steps_agree(B, T):
     for n in res[0][1]:
         assert_close(res[1][1][n], res[0][1][n], 1e-5, f"grad {n}", atol=1e-9)
         assert_close(res[1][2][n], res[0][2][n], 1e-5, n)
+
+
+def test_critic_update_at_full_size_matches_reference_golden(golden):
+    """BASELINE's shape for this variant, B = 128, L = 1024, V = 175 (ragged lengths, no dropout): one critic
+    update of the reference's own CWGAN.train_step (g14) against critic_step through the two-layer stack sweeps
+    (s2g_k_lstm64_stack_fwd / _bwd over 1 024 steps), the token tables and the bucketed sums: loss, every
+    gradient (norm-wise and element by element), the clamped parameters and what the Adam step moved."""
+    Gd = golden("g14_wgan_clip_full_size.pt")
+    V, B, T = 175, 128, 1024
+    D, G, pd, _ = engines(1801, V)
+    tokens, labels, lengths = common.batch(1810, B, T, vocab=V, min_len=64)
+    g = common.gen(1820)
+    noise = torch.randint(0, V, (B, 100), generator=g)
+    U = torch.rand((B, 100, V), generator=g)
+    fake = G.forward(noise.to(torch.int32).to(DEV), labels.to(DEV), 0.5, U=U.to(DEV))
+    loss = D.critic_step(tokens.to(torch.int32).to(DEV).contiguous(), labels.to(DEV), lengths.to(torch.int32).to(DEV),
+                         int(lengths.max()), fake, 2e-4, 0.5, 0.999, 0.1, masks_real=None, masks_fake=None)
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(Gd["d_loss"])) < TOL * max(1.0, abs(float(Gd["d_loss"])))
+    for n, gv in D.grads.views.items():
+        assert_close(gv, Gd[f"grad.{n}"], TOL, f"grad {n}", atol=1e-9)
+    for n, v in D.params.views.items():
+        assert_close(v, Gd[f"D.{n}"], TOL, n)
+        if n != "linear.bias":          # d(loss)/d(linear.bias) = -1 + 1 = 0: the reference never moves it
+            assert_update_close(v, pd[n], Gd[f"D.{n}"], TOL, n)
+
+
+def test_relaxed_embedding_and_attention_modules_match_reference_golden(golden):
+    """RelaxedEmbedding.forward (both branches) and Attention.forward of wgan.py with their gradients (g15)."""
+    import wgan as W
+    Gd = golden("g15_wgan_modules.pt")
+    V = 175
+    pd, _ = common.wgan_clip_params(1901, V)
+    emb = W.RelaxedEmbedding(V, 32).to(DEV)
+    with torch.no_grad():
+        emb.embed_layer.weight.copy_(pd["sequence_embedding.embed_layer.weight"])
+    dy = Gd["emb.dy"].to(DEV)
+    y = emb(Gd["emb.tok"].to(DEV))
+    (gw,) = torch.autograd.grad(y, [emb.embed_layer.weight], dy)
+    assert_close(y, Gd["emb.y_tok"], 1e-6, "lookup")
+    assert_close(gw, Gd["emb.dW_tok"], 1e-5, "lookup d(table)", atol=1e-9)
+    x = Gd["emb.soft"].to(DEV).requires_grad_(True)
+    y = emb(x)
+    gw, gx = torch.autograd.grad(y, [emb.embed_layer.weight, x], dy)
+    assert_close(y, Gd["emb.y_soft"], TOL, "matmul branch")
+    assert_close(gw, Gd["emb.dW_soft"], TOL, "matmul d(table)")
+    assert_close(gx, Gd["emb.dx_soft"], TOL, "matmul d(x)")
+    att = W.Attention(64).to(DEV)
+    with torch.no_grad():
+        att.attn.weight.copy_(pd["attention.attn.weight"]); att.attn.bias.copy_(pd["attention.attn.bias"])
+        att.context_vector.weight.copy_(pd["attention.context_vector.weight"])
+    hidden = Gd["att.hidden"].to(DEV).requires_grad_(True)
+    lo = Gd["att.lstm_outputs"].to(DEV).requires_grad_(True)
+    pooled, weights = att(hidden, lo)
+    grads = torch.autograd.grad([pooled, weights], [hidden, lo, att.attn.weight, att.attn.bias, att.context_vector.weight],
+                                [Gd["att.d_pooled"].to(DEV), Gd["att.d_weights"].to(DEV)])
+    assert_close(pooled, Gd["att.pooled"], TOL, "pooled")
+    assert_close(weights, Gd["att.weights"], TOL, "weights")
+    for n, gv in zip(("d_hidden", "d_lstm_outputs", "d_attn_w", "d_attn_b", "d_context"), grads):
+        assert_close(gv, Gd[f"att.{n}"], TOL, n)
+
+
+def test_discriminator_forward_is_differentiable_and_train_anneals_like_the_reference(golden):
+    """Discriminator.forward of wgan.py under autograd (token input: gradients of every parameter; relaxed input:
+    also the input gradient) and CWGAN.train with tau annealing, against the reference's own run (g15)."""
+    import argparse
+    import contextlib
+    import io
+    import wgan as W
+    Gd = golden("g15_wgan_modules.pt")
+    V = 175
+    pd, pg = common.wgan_clip_params(1901, V)
+    D = W.Discriminator(V, 2, 2, dropout=0.0).to(DEV)
+    D.load_state_dict(pd)
+    tokens, labels, lengths = Gd["D.tokens"], Gd["D.labels"], Gd["D.lengths"]
+    dval = Gd["D.dval"].to(DEV)
+    val = D(tokens.to(DEV), labels.to(DEV), lengths)
+    names = [n for n, _ in D.named_parameters()]
+    gt = torch.autograd.grad(val, [q for _, q in D.named_parameters()], dval)
+    assert_close(val, Gd["D.val_tok"], TOL, "D(tokens)")
+    for n, gv in zip(names, gt):
+        assert_close(gv, Gd[f"D.grad_tok.{n}"], TOL, f"token input, grad {n}", atol=1e-9)
+    x = Gd["D.soft"].to(DEV).requires_grad_(True)
+    full = torch.full((tokens.shape[0],), tokens.shape[1], dtype=torch.long)
+    val2 = D(x, labels.to(DEV), full)
+    gs = torch.autograd.grad(val2, [x] + [q for _, q in D.named_parameters()], dval)
+    assert_close(val2, Gd["D.val_soft"], TOL, "D(relaxed)")
+    assert_close(gs[0], Gd["D.dx_soft"], TOL, "d D / d relaxed input")
+    for n, gv in zip(names, gs[1:]):
+        assert_close(gv, Gd[f"D.grad_soft.{n}"], TOL, f"relaxed input, grad {n}", atol=1e-9)
+    # CWGAN.train
+    G2 = W.Generator(V, 2, 3, softmax="gumbel_softmax")
+    D2 = W.Discriminator(V, 2, 2, dropout=0.0)
+    G2.load_state_dict(pg); D2.load_state_dict(pd)
+    opt = argparse.Namespace(lr=2e-4, beta1=0.5, beta2=0.999, clip_value=0.1, n_critic=5)
+    model = W.CWGAN(G2, D2, opt)
+    noises, Us = list(Gd["train.noise"]), list(Gd["train.U"])
+    real_randint, real_rand = torch.randint, torch.rand
+    torch.randint = lambda *a, **k: noises.pop(0).clone()
+    torch.rand = lambda *a, **k: Us.pop(0).clone()
+    buf = io.StringIO()
+    try:
+        with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(io.StringIO()):
+            model.train([(tokens, labels, lengths)], epochs=3, tau=0.5, hard=False, anneal_tau=True, anneal_interval=1)
+    finally:
+        torch.randint, torch.rand = real_randint, real_rand
+    got = torch.tensor(model.losses["d_loss"], dtype=torch.float64)
+    assert torch.allclose(got, Gd["train.d_losses"], rtol=TOL, atol=1e-5), (got, Gd["train.d_losses"])
+    assert model.losses["g_loss"] == [0.0, 0.0, 0.0]
+    ref_lines, our_lines = Gd["train.printed"].strip().splitlines(), buf.getvalue().strip().splitlines()
+    assert len(ref_lines) == len(our_lines) == 6
+    for a, b in zip(our_lines, ref_lines):
+        if a.startswith("epoch"):
+            assert a == b, (a, b)          # the annealed tau, printed with full precision
+        else:
+            assert a.split("|")[0] == b.split("|")[0] and a.split("|")[2] == b.split("|")[2], (a, b)
+            assert abs(float(a.split("Discriminator Loss:")[1].split("|")[0]) -
+                       float(b.split("Discriminator Loss:")[1].split("|")[0])) <= 2e-5, (a, b)
+    for n, v in D2.state_dict().items():
+        assert_close(v, Gd[f"train.D.{n}"], TOL, f"after train: {n}")
+    assert isinstance(model.eval(), W.CWGAN) and not model.training          # nn.Module.train(False) still works
