@@ -129,6 +129,11 @@ int s2g_generate_tokens(const float* W, const float* x, const float* bias, const
  * problems that read the same rows of an operand find them in L2. */
 int s2g_gemm_grouped(const S2GGemm* table_dev, const int* prefix_dev, int nprob, int total_blocks, int nz,
                      void* stream);
+/* The same launch with both operands rounded to bf16 and fp32 accumulation (v_mfma_f32_16x16x32_bf16): the
+ * reduced-precision form of the weight gradients (autograd of the W_ih / W_hh products of nn.LSTM, wgan_gp.py:189,
+ * 317) for the 2e-2 path; same tables, block order and slabs; every kchunk a multiple of 32. */
+int s2g_gemm_grouped_bf16(const S2GGemm* table_dev, const int* prefix_dev, int nprob, int total_blocks, int nz,
+                          void* stream);
 int s2g_reduce_slabs(const float* slabs, long slab, int nslab, int rows, int cols, float* out,
                      int permute_rows, int accumulate, float scale, void* stream);
 /* up to 8 such reductions in one launch; `jobs` is a HOST array (copied into the kernel arguments) */

@@ -112,3 +112,165 @@ extern "C" int s2g_launch_gemm_tall_bf16(const float* A, long lda, const float* 
 #undef S2G_TALLB_CASE
   return -1;
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// bf16-operand form of the grouped weight-gradient product (s2g_k_gemm_grouped, gemm.hip): the same problems,
+// block order and split-K slabs, C[0:M, n0:n0+64] += sum_k A[k][m] B[k][n] over one K-chunk with M <= 208, but the
+// operands are rounded to bf16 (fp32 accumulation) and multiplied on v_mfma_f32_16x16x32_bf16.  Both MFMA
+// operands want 8 CONSECUTIVE k per lane while memory is k-major (a saved row per k), so the tiles are transposed on
+// their way into LDS: wave w fetches rows k0 + 8w .. 8w + 7 of the chunk (row index wave-uniform: the scalar row
+// stepper of the fp32 kernel), lane = m-quad (A, 16-byte loads) / column (B); the eight values a lane holds for one
+// m (or n) are exactly one fragment piece = one 16-byte LDS write at At[m][8 slot].  slot = (w + (m >> 2)) & 3
+// spreads the fragment READS of 16 consecutive m over all 64 banks (the writes of A take a 4-way conflict: all
+// lanes of an instruction share m mod 4).  With 1/16 of the fp32 matrix time the kernel is bound by its loads.
+#define GB_MT 13                     // 16-row tiles: M <= 208
+__device__ __forceinline__ void wgrad_tile_bf16(const GemmArgs& g, const int bx, const int bz, __bf16* At, __bf16* Bt) {
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int n0 = bx * 64;
+  const int kbeg = bz * g.kchunk;
+  const int kend = min(g.K, kbeg + g.kchunk);
+  const int segT = g.segT;
+
+  const bool a_in = 4 * lane + 3 < g.M;                  // M % 4 == 0: a quad is inside or outside as a whole
+  const unsigned a_lane = a_in ? 4 * lane : 0;
+  const int ncol = n0 + lane;
+  const bool b_in = ncol < g.N;
+  const long b_lane = b_in ? (long)ncol * g.sbn : 0;
+
+  // scalar row stepper over the rows this wave fetches: kbeg + 8 w + j (j = 0..7), then + 32 per chunk
+  int rk = kbeg + 8 * wave, rb = 0, rt = rk;
+  if (segT > 0) { rb = rk / segT; rt = rk - rb * segT; }
+  const long shiftB = g.shift ? 1 : 0;
+  const float *pa, *pb;
+  auto rowptrs = [&]() {
+    const long rowA = segT > 0 ? (long)rb * g.a_seg + rt : (long)rk;
+    const long rowB = (segT > 0 ? (long)rb * g.b_seg + rt : (long)rk) - shiftB;
+    pa = g.A + rowA * g.sak;
+    pb = g.B + rowB * g.sbk;          // with shift at rt == 0 this is never dereferenced
+  };
+  rowptrs();
+  auto advance = [&](int d) {
+    rk += d; rt += d;
+    if (segT > 0 && rt >= segT) {
+      do { rt -= segT; ++rb; } while (rt >= segT);
+      rowptrs();
+    } else {
+      pa += d * g.sak; pb += d * g.sbk;
+    }
+  };
+
+  float4 ra[8];
+  float rbv[8];
+  unsigned okA = 0, okB = 0;          // scalar masks: row j exists for A / B
+  auto fetch = [&](int j) {           // row rk -> slot j, then on to the next row of this wave
+    const bool in = rk < kend;
+    const bool inB = in && !(g.shift && rt == 0);
+    ra[j] = gload4((in ? pa : g.A) + a_lane);
+    rbv[j] = gload((inB ? pb : g.B) + b_lane);
+    if (j == 0) { okA = 0; okB = 0; }
+    okA |= in ? (1u << j) : 0u;
+    okB |= inB ? (1u << j) : 0u;
+    advance(j == 7 ? 25 : 1);
+  };
+  const int aslot = (wave + lane) & 3;                   // m = 4 lane + c: (m >> 2) = lane
+  const int bslot = (wave + (lane >> 2)) & 3;
+  auto store = [&]() {
+    f32x8 va[4], vb;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool la = a_in && ((okA >> j) & 1u), lb = b_in && ((okB >> j) & 1u);
+      va[0][j] = la ? ra[j].x : 0.0f; va[1][j] = la ? ra[j].y : 0.0f;
+      va[2][j] = la ? ra[j].z : 0.0f; va[3][j] = la ? ra[j].w : 0.0f;
+      vb[j] = lb ? rbv[j] : 0.0f;
+    }
+    if (lane < GB_MT * 4) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        *reinterpret_cast<bf16x8*>(At + (4 * lane + c) * 32 + 8 * aslot) = __builtin_convertvector(va[c], bf16x8);
+    }
+    *reinterpret_cast<bf16x8*>(Bt + lane * 32 + 8 * bslot) = __builtin_convertvector(vb, bf16x8);
+  };
+
+  f32x4b acc[GB_MT];
+#pragma unroll
+  for (int i = 0; i < GB_MT; ++i) acc[i] = (f32x4b){0.0f, 0.0f, 0.0f, 0.0f};
+  const int fi = lane & 15, kg = lane >> 4;
+  const bool wave_live = n0 + 16 * wave < g.N;           // a column tile past N: nothing to multiply or store
+  const int bn = 16 * wave + fi;
+  const __bf16* bfrag = Bt + bn * 32 + 8 * ((kg + (bn >> 2)) & 3);
+
+  if (kbeg < kend) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) fetch(j);
+    store();
+    __syncthreads();
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
+      // the next chunk's row fetches are issued in front of this chunk's MFMAs (past the last chunk they read
+      // element 0 and are discarded)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) fetch(j);
+      if (wave_live) {
+        const bf16x8 bq = *reinterpret_cast<const bf16x8*>(bfrag);
+#pragma unroll
+        for (int i = 0; i < GB_MT; ++i) {
+          const int m = 16 * i + fi;
+          const bf16x8 aq = *reinterpret_cast<const bf16x8*>(At + m * 32 + 8 * ((kg + (m >> 2)) & 3));
+          acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq, bq, acc[i], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+      if (k0 + 32 < kend) {
+        store();
+        __syncthreads();
+      }
+    }
+  }
+
+  if (!wave_live) return;
+  float* C = g.C + (long)bz * g.slab;
+  const int col = n0 + 16 * wave + fi;
+  if (col < g.N) {
+#pragma unroll
+    for (int i = 0; i < GB_MT; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * i + 4 * kg + r;
+        if (row < g.M) C[(long)row * g.ldc + col] = g.alpha * acc[i][r];
+      }
+    }
+  }
+}
+
+extern "C" __global__ __launch_bounds__(256) void s2g_k_gemm_grouped_bf16(const GemmArgs* __restrict__ table,
+                                                                          const int* __restrict__ prefix, int nprob,
+                                                                          int nz) {
+  __shared__ __attribute__((aligned(16))) __bf16 At[16 * GB_MT * 32];
+  __shared__ __attribute__((aligned(16))) __bf16 Bt[64 * 32];
+  // block -> (problem, tile, K-chunk): the mapping of s2g_k_gemm_grouped (one XCD works through a contiguous range
+  // of logical blocks; K-chunk first across all problems when nz > 0)
+  const int total = gridDim.x, q = total >> 3, r = total & 7;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  int p = 0;
+  if (nz > 0) {
+    const int tiles = prefix[nprob];
+    const int bz = lid / tiles, t = lid - bz * tiles;
+    while (p + 1 < nprob && t >= prefix[p + 1]) ++p;
+    const GemmArgs gs = table[p];
+    wgrad_tile_bf16(gs, t - prefix[p], bz, At, Bt);
+    return;
+  }
+  while (p + 1 < nprob && lid >= prefix[p + 1]) ++p;
+  const GemmArgs gs = table[p];
+  const int local = lid - prefix[p];
+  const int nx = (gs.N + 63) / 64;
+  wgrad_tile_bf16(gs, local % nx, local / nx, At, Bt);
+}
+
+extern "C" int s2g_launch_gemm_grouped_bf16(const GemmArgs* table_dev, const int* prefix_dev, int nprob,
+                                            int total_blocks, int nz, hipStream_t stream) {
+  hipLaunchKernelGGL(s2g_k_gemm_grouped_bf16, dim3(total_blocks), dim3(256), 0, stream, table_dev, prefix_dev, nprob,
+                     nz);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}

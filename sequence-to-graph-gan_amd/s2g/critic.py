@@ -79,7 +79,8 @@ class CriticEngine:
         self.overlap = True           # run the work that does not depend on sweeps C/D beside them (critic_iteration)
         self._side = None             # (stream, fork event, join event, scratch) of that second stream
         self.stream_g = None          # CU-masked stream of the prefetch hook (created with _side)
-        self.bf16 = False             # tall products of the input layer on bf16 MFMA (2e-2 path); default exact fp32
+        self.bf16 = False             # tall products of the input layer and the weight-gradient products on bf16 MFMA
+                                      # (fp32 accumulation; the 2e-2 path); default exact fp32
         self.reserve_comm_stream = False   # data-parallel runs: the collective library owns a stream (and a hardware
                                            # queue) of its own, so the prefetch hook shares the second stream instead
         self._m2_events = None        # (weights packed, M2 built) when M2 is built on a side stream
@@ -486,8 +487,9 @@ def _wgrad_launch(eng: "CriticEngine", built, phase: int) -> None:
     t = built[0].get(phase)
     if t is not None:
         raw, pre, nprob, nblocks, nz = t
+        fn = "s2g_gemm_grouped_bf16" if eng.bf16 else "s2g_gemm_grouped"
         eng.timed(f"s2g_k_gemm_grouped#{phase}",
-                  lambda: call("s2g_gemm_grouped", ptr(raw), ptr(pre), nprob, nblocks, nz, stream_ptr()))
+                  lambda: call(fn, ptr(raw), ptr(pre), nprob, nblocks, nz, stream_ptr()))
 
 
 def _wgrad_reduce(eng: "CriticEngine", built, early: bool = False) -> None:

@@ -42,21 +42,25 @@ def test_gemm_tall_rejects_bad_shapes():
     assert L.s2g_gemm_tall(x.data_ptr(), 200, x.data_ptr(), 256, x.data_ptr(), 256, 64, 230, 200, s) == -1   # N > 224
 
 
-def test_gemm_grouped_matches_torch():
+@pytest.mark.parametrize("fn,tol", [("s2g_gemm_grouped", 1e-5), ("s2g_gemm_grouped_bf16", 1e-5)])
+def test_gemm_grouped_matches_torch(fn, tol):
     """Three weight-gradient products in one launch: a wide one on contiguous rows with a ragged K, a
     narrow one whose B operand is strided (every 4th float) and reads the previous step inside each
-    sequence (zero at step 0), and a wide one whose operands keep a different number of rows per sequence."""
+    sequence (zero at step 0), and a wide one whose operands keep a different number of rows per sequence.
+    The bf16 form is held to the same bound against a float64 product of the bf16-ROUNDED operands (its
+    only other difference from the fp32 form is the order of the fp32 additions)."""
     from s2g.lib import S2GGemm, call
     from s2g.ops import ptr, stream_ptr
     g = common.gen(21)
     nb, T, Tw = 5, 37, 41
     K1 = 1003
-    A1 = torch.randn(K1, 200, generator=g).to(DEV)
-    B1 = torch.randn(K1, 175, generator=g).to(DEV)
-    A2 = torch.randn(nb * Tw, 200, generator=g).to(DEV)
-    cell = torch.randn(nb * Tw, 50, 4, generator=g).to(DEV)
-    A3 = torch.randn(nb * Tw, 200, generator=g).to(DEV)
-    B3 = torch.randn(nb * T, 175, generator=g).to(DEV)
+    rnd = (lambda t: t.bfloat16().float()) if fn.endswith("bf16") else (lambda t: t)
+    A1 = rnd(torch.randn(K1, 200, generator=g)).to(DEV)
+    B1 = rnd(torch.randn(K1, 175, generator=g)).to(DEV)
+    A2 = rnd(torch.randn(nb * Tw, 200, generator=g)).to(DEV)
+    cell = rnd(torch.randn(nb * Tw, 50, 4, generator=g)).to(DEV)
+    A3 = rnd(torch.randn(nb * Tw, 200, generator=g)).to(DEV)
+    B3 = rnd(torch.randn(nb * T, 175, generator=g)).to(DEV)
     want1 = A1.double().T @ B1.double()
     h = cell[:, :, 2].double().view(nb, Tw, 50)
     hprev = torch.zeros_like(h)
@@ -78,10 +82,10 @@ def test_gemm_grouped_matches_torch():
     prefix.append(blocks)
     raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(DEV)
     pre = torch.tensor(prefix, dtype=torch.int32, device=DEV)
-    call("s2g_gemm_grouped", ptr(raw), ptr(pre), len(probs), blocks, 0, stream_ptr())
+    call(fn, ptr(raw), ptr(pre), len(probs), blocks, 0, stream_ptr())
     torch.cuda.synchronize()
     for out, want in zip(outs, (want1, want2, want3)):
-        assert rel(out.double().sum(0), want) < 1e-5
+        assert rel(out.double().sum(0), want) < tol
 
     # K-chunk-first block order: every problem cut into the same number of chunks, prefix counts tiles
     K = nb * Tw
@@ -101,11 +105,11 @@ def test_gemm_grouped_matches_torch():
     prefix.append(tiles)
     raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(DEV)
     pre = torch.tensor(prefix, dtype=torch.int32, device=DEV)
-    call("s2g_gemm_grouped", ptr(raw), ptr(pre), len(probs), tiles * nz, nz, stream_ptr())
+    call(fn, ptr(raw), ptr(pre), len(probs), tiles * nz, nz, stream_ptr())
     torch.cuda.synchronize()
     wants = (want2, A2.double().T @ B1.double()[:K], A3.double().T @ cell[:, :, 1].double())
     for out, want in zip(outs, wants):
-        assert rel(out.double().sum(0), want) < 1e-5
+        assert rel(out.double().sum(0), want) < tol
 
 
 def test_dropout_mask_matches_torch():
