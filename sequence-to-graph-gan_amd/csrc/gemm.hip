@@ -948,10 +948,7 @@ extern "C" __global__ __launch_bounds__(64 * WS_WAVES) void s2g_k_linear_wstream
 // in-kernel sampler's numbering (counter (m * L + t) * 64 + v / 4, word v % 4).
 #include "rng.hip"
 #define GT_MAXTILES 48
-__device__ __forceinline__ float gumbel_of(float u) {
-  const float uu = 1e-10f + (1.0f - 1e-10f) * u;
-  return -logf(-logf(uu + 1e-20f) + 1e-20f);
-}
+__device__ __forceinline__ float gumbel_of(float u) { return gumbel_noise(u); }
 extern "C" __global__ __launch_bounds__(64 * WS_WAVES) void s2g_k_generate_tokens(
     const float* __restrict__ W, const float* __restrict__ X, const float* __restrict__ bias,
     const float* __restrict__ U, long long* __restrict__ tokens, int L, int V, int M, int K, int TS,

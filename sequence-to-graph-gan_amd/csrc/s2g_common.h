@@ -136,6 +136,20 @@ __device__ __forceinline__ float fast_tanh(float x) {
   return 2.0f * __builtin_amdgcn_rcpf(1.0f + e) - 1.0f;
 }
 
+// Gumbel noise of one uniform draw, as CustomSoftmax.sample_gumbel computes it in fp32 (wgan_gp.py:58-61):
+// u' = 1e-10 + (1 - 1e-10) u;  g = -log(-log(u' + 1e-20) + 1e-20).  Both logarithms on the hardware's v_log_f32
+// (log2, ~1 ulp) times ln 2: u' >= 1e-10 and -log u' >= 6e-8 are normal numbers, so no range handling is needed,
+// and the result differs from the library logf by a few ulp of a value that is ADDED to a logit (the library
+// form costs ~20 instructions per logarithm, which made the sampler VALU-bound).  Every kernel that perturbs
+// logits uses this one function, so the fused decode and the sampler agree on every argmax.
+__device__ __forceinline__ float gumbel_noise(float u) {
+  const float uu = 1e-10f + (1.0f - 1e-10f) * u;
+  const float inner = -0.6931471805599453f * __builtin_amdgcn_logf(uu + 1e-20f) + 1e-20f;
+  return -0.6931471805599453f * __builtin_amdgcn_logf(inner);
+}
+// exp(x) for x <= 0 (softmax numerators after the row maximum is subtracted): v_exp_f32 (2^x, ~1 ulp)
+__device__ __forceinline__ float exp_nonpos(float x) { return __builtin_amdgcn_exp2f(1.4426950408889634f * x); }
+
 // storage position of hidden unit k (or gate row j) in an LDS vector cut into slices of 13
 // values, each slice padded to 16 floats so a lane fetches its slice with 16-byte reads
 __device__ __forceinline__ int pos13(int k) { return ((k / 13) << 4) + (k % 13); }

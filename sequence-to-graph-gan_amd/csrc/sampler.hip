@@ -48,8 +48,7 @@ extern "C" __global__ __launch_bounds__(256) void s2g_k_gumbel_softmax_fwd(
       float x = lg[j];
       if (bs) x += bs[j];
       if (mode == 0) {
-        float u = 1e-10f + (1.0f - 1e-10f) * U[row * V + j];
-        x += -logf(-logf(u + 1e-20f) + 1e-20f);
+        x += gumbel_noise(U[row * V + j]);
       }
       z[e] = (mode == 2) ? x : x * inv_tau;
       mx = fmaxf(mx, z[e]);
@@ -60,7 +59,7 @@ extern "C" __global__ __launch_bounds__(256) void s2g_k_gumbel_softmax_fwd(
 #pragma unroll
   for (int e = 0; e < MAXPER; ++e) {
     int j = lane + 64 * e;
-    z[e] = (j < V) ? expf(z[e] - mx) : 0.0f;
+    z[e] = (j < V) ? exp_nonpos(z[e] - mx) : 0.0f;
     sum += z[e];
   }
   sum = wave_sum(sum);
@@ -196,10 +195,7 @@ __global__ __launch_bounds__(256) void s2g_k_gumbel_softmax_fwd_v4(
         u[r][0] = u01(q.x); u[r][1] = u01(q.y); u[r][2] = u01(q.z); u[r][3] = u01(q.w);
       }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float uu = 1e-10f + (1.0f - 1e-10f) * u[r][k];
-        z[r][k] += -logf(-logf(uu + 1e-20f) + 1e-20f);
-      }
+      for (int k = 0; k < 4; ++k) z[r][k] += gumbel_noise(u[r][k]);
     }
     float mx = -INFINITY;
 #pragma unroll
@@ -211,7 +207,7 @@ __global__ __launch_bounds__(256) void s2g_k_gumbel_softmax_fwd_v4(
     float sum = 0.0f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      z[r][k] = k < nv ? expf(z[r][k] - mx) : 0.0f;
+      z[r][k] = k < nv ? exp_nonpos(z[r][k] - mx) : 0.0f;
       sum += z[r][k];
     }
     sum = wave_sum(sum);
