@@ -289,6 +289,17 @@ int s2g_embed_mul(const float* z, const long long* labels, const float* emb, flo
 int s2g_embed_mul_bwd(const float* z, const long long* labels, const float* dout, float* demb, int B, int D,
                       int n_classes, void* stream);
 int s2g_lrelu_bwd(const float* y, float* dy, long n, void* stream);
+/* ---- transformer encoder layer pieces (reference transformer.py:285-317, CustomTransformerEncoderLayer.forward).
+ * F.relu of the feed-forward block (:309) is the GEMM epilogue act = 2; its backward: dy <- y > 0 ? dy : 0. */
+int s2g_relu_bwd(const float* y, float* dy, long n, void* stream);
+/* src = norm(src + dropout(src2)) (:305-306, :310-311): y = LayerNorm(x + r * rmask) over the E <= 1024 features of
+ * each of `rows` rows (r, rmask NULL: no residual / no dropout multiplier); xhat [rows, E] and rstd [rows] (may be
+ * NULL) are saved for the backward.  nn.LayerNorm arithmetic: biased variance, eps inside the root. */
+int s2g_add_layernorm_fwd(const float* x, const float* r, const float* rmask, const float* gamma, const float* beta,
+                          float eps, float* y, float* xhat, float* rstd, long rows, int E, void* stream);
+/* dz = d loss / d (x + r * rmask) from dy; dyxh = dy * xhat (column sums: d gamma; those of dy: d beta). */
+int s2g_add_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, float* dz,
+                          float* dyxh, long rows, int E, void* stream);
 /* inter-layer dropout of nn.LSTM(175, 50, 2, dropout=p) in train mode (wgan_gp.py:189): uniform draws
  * u[rows][52] -> multiplier (u >= p) / (1 - p) in place, columns 50 and 51 (row padding) -> 0 */
 int s2g_dropout_mask(float* u, long rows, float p, void* stream);

@@ -24,3 +24,25 @@ def attention_forward(values, keys, queries, in_w, in_b, out_w, out_b, num_heads
     if batch_first:                                                           # :279-280
         out = out.transpose(0, 1)
     return out
+
+
+def encoder_layer_forward(x, p, num_heads, attn_mask=None, pad_mask=None, masks=(None, None, None), eps=1e-5):
+    """CustomTransformerEncoderLayer.forward (reference transformer.py:298-317) for x [N, T, E] (dim 0 = what the
+    attention module treats as the batch) in plain torch ops of x's dtype; p: the layer's parameters under their
+    state_dict names; masks = (m1, m_ffn, m2): the three dropout multipliers (None: no dropout).
+    Test infrastructure only: the product path never imports this module."""
+    import torch.nn.functional as F
+    m1, mf, m2 = masks
+    src2 = attention_forward(x, x, x, p["attn.in_proj_weight"], p["attn.in_proj_bias"], p["attn.fc_out.weight"],
+                             p["attn.fc_out.bias"], num_heads, attn_mask, pad_mask)
+    if m1 is not None:
+        src2 = src2 * m1
+    E = x.shape[-1]
+    src = F.layer_norm(x + src2, (E,), p["norm1.weight"], p["norm1.bias"], eps)
+    h = F.relu(F.linear(src, p["linear1.weight"], p["linear1.bias"]))
+    if mf is not None:
+        h = h * mf
+    src2 = F.linear(h, p["linear2.weight"], p["linear2.bias"])
+    if m2 is not None:
+        src2 = src2 * m2
+    return F.layer_norm(src + src2, (E,), p["norm2.weight"], p["norm2.bias"], eps)

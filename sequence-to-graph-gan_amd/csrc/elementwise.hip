@@ -41,6 +41,93 @@ extern "C" __global__ void s2g_k_lrelu_bwd(const float* __restrict__ y, float* _
   if (i < n) dy[i] = y[i] > 0.0f ? dy[i] : 0.2f * dy[i];
 }
 
+// backward of ReLU (fused into the GEMM epilogue as act = 2): dy <- y > 0 ? dy : 0
+extern "C" __global__ void s2g_k_relu_bwd(const float* __restrict__ y, float* __restrict__ dy, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dy[i] = y[i] > 0.0f ? dy[i] : 0.0f;
+}
+
+// ---- residual + LayerNorm of a transformer encoder layer (reference transformer.py:305-312:
+// src = norm(src + dropout(src2))).  z = x + r (* rmask, the dropout multiplier, when given); y = LayerNorm(z) =
+// (z - mean) rstd * gamma + beta with the biased variance over the E features of a row (nn.LayerNorm, eps
+// inside the root).  One wavefront per row, lane l owns features l, l + 64, ...; two-pass mean / variance.
+// Saves xhat = (z - mean) rstd and rstd for the backward.
+#define LN_MAXPER 16      // E <= 1024
+extern "C" __global__ __launch_bounds__(256) void s2g_k_add_layernorm_fwd(
+    const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ rmask,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float* __restrict__ y,
+    float* __restrict__ xhat, float* __restrict__ rstd, long rows, int E) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const long base = row * E;
+  float z[LN_MAXPER];
+  float sum = 0.0f;
+#pragma unroll
+  for (int e = 0; e < LN_MAXPER; ++e) {
+    const int j = lane + 64 * e;
+    z[e] = 0.0f;
+    if (j < E) {
+      float rv = r ? r[base + j] : 0.0f;
+      if (rmask) rv *= rmask[base + j];
+      z[e] = x[base + j] + rv;
+    }
+    sum += z[e];
+  }
+  const float mean = wave_sum(sum) / (float)E;
+  float sq = 0.0f;
+#pragma unroll
+  for (int e = 0; e < LN_MAXPER; ++e) {
+    const int j = lane + 64 * e;
+    const float d = j < E ? z[e] - mean : 0.0f;
+    sq = fmaf(d, d, sq);
+  }
+  const float rs = 1.0f / sqrtf(wave_sum(sq) / (float)E + eps);
+#pragma unroll
+  for (int e = 0; e < LN_MAXPER; ++e) {
+    const int j = lane + 64 * e;
+    if (j < E) {
+      const float xh = (z[e] - mean) * rs;
+      if (xhat) xhat[base + j] = xh;
+      y[base + j] = fmaf(xh, gamma[j], beta[j]);
+    }
+  }
+  if (rstd && lane == 0) rstd[row] = rs;
+}
+
+// its backward: g = dy gamma; dz = rstd (g - mean(g) - xhat mean(g xhat)) (= d/dx and, times rmask, d/dr);
+// dyxh = dy xhat, whose column sums are d(gamma) (those of dy are d(beta)).
+extern "C" __global__ __launch_bounds__(256) void s2g_k_add_layernorm_bwd(
+    const float* __restrict__ dy, const float* __restrict__ xhat, const float* __restrict__ rstd,
+    const float* __restrict__ gamma, float* __restrict__ dz, float* __restrict__ dyxh, long rows, int E) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const long base = row * E;
+  float g[LN_MAXPER], xh[LN_MAXPER];
+  float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+  for (int e = 0; e < LN_MAXPER; ++e) {
+    const int j = lane + 64 * e;
+    g[e] = 0.0f; xh[e] = 0.0f;
+    if (j < E) {
+      const float d = dy[base + j];
+      xh[e] = xhat[base + j];
+      g[e] = d * gamma[j];
+      dyxh[base + j] = d * xh[e];
+    }
+    s1 += g[e];
+    s2 = fmaf(g[e], xh[e], s2);
+  }
+  const float m1 = wave_sum(s1) / (float)E, m2 = wave_sum(s2) / (float)E;
+  const float rs = rstd[row];
+#pragma unroll
+  for (int e = 0; e < LN_MAXPER; ++e) {
+    const int j = lane + 64 * e;
+    if (j < E) dz[base + j] = rs * (g[e] - m1 - xh[e] * m2);
+  }
+}
+
 // Inter-layer dropout multiplier of nn.LSTM(dropout=p) in train mode (wgan_gp.py:189): from uniform
 // draws u[rows][52] to m = (u >= p) / (1 - p) in place; columns 50, 51 are row padding and become 0.
 // One float4 (= 4 columns of one row, 52 % 4 == 0) per thread.

@@ -244,6 +244,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
         long off = (long)row * g.ldc + col;
         if (g.accumulate) v += C[off];
         if (g.act == 1) v = v > 0.0f ? v : 0.2f * v;
+        else if (g.act == 2) v = fmaxf(v, 0.0f);
         C[off] = v;
       }
     }

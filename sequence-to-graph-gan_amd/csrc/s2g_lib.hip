@@ -492,6 +492,26 @@ int s2g_lrelu_bwd(const float* y, float* dy, long n, void* stream) {
   hipLaunchKernelGGL(s2g_k_lrelu_bwd, dim3(cdiv(n, 256)), dim3(256), 0, ST(stream), y, dy, n);
   return LAUNCH_OK();
 }
+int s2g_relu_bwd(const float* y, float* dy, long n, void* stream) {
+  if (!y || !dy || n <= 0) return -1;
+  hipLaunchKernelGGL(s2g_k_relu_bwd, dim3(cdiv(n, 256)), dim3(256), 0, ST(stream), y, dy, n);
+  return LAUNCH_OK();
+}
+int s2g_add_layernorm_fwd(const float* x, const float* r, const float* rmask, const float* gamma, const float* beta,
+                          float eps, float* y, float* xhat, float* rstd, long rows, int E, void* stream) {
+  if (!x || !gamma || !beta || !y || rows <= 0 || E <= 0 || E > 64 * LN_MAXPER || !(eps >= 0.0f)) return -1;
+  if (rmask && !r) return -1;
+  hipLaunchKernelGGL(s2g_k_add_layernorm_fwd, dim3(cdiv(rows, 4)), dim3(256), 0, ST(stream), x, r, rmask, gamma, beta,
+                     eps, y, xhat, rstd, rows, E);
+  return LAUNCH_OK();
+}
+int s2g_add_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, float* dz,
+                          float* dyxh, long rows, int E, void* stream) {
+  if (!dy || !xhat || !rstd || !gamma || !dz || !dyxh || rows <= 0 || E <= 0 || E > 64 * LN_MAXPER) return -1;
+  hipLaunchKernelGGL(s2g_k_add_layernorm_bwd, dim3(cdiv(rows, 4)), dim3(256), 0, ST(stream), dy, xhat, rstd, gamma, dz,
+                     dyxh, rows, E);
+  return LAUNCH_OK();
+}
 int s2g_dropout_mask(float* u, long rows, float p, void* stream) {
   if (!u || rows <= 0 || !(p >= 0.0f) || !(p < 1.0f) || ((uintptr_t)u & 15)) return -1;
   const long n4 = rows * (S2G_MASKW / 4);

@@ -93,3 +93,116 @@ class MultiheadAttentionFn(torch.autograd.Function):
         dx3 = dx3.view(N, T, 3 * E)
         dq, dk, dv = dx3[..., :E], dx3[..., E:2 * E], dx3[..., 2 * E:]
         return dv, dk, dq, None, None, d_in_w, d_in_b, d_out_w, d_out_b, None
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# The pieces CustomTransformerEncoderLayer.forward puts around the attention module (transformer.py:298-317):
+# residual + LayerNorm, the feed-forward Linears with ReLU, the dropout multipliers.  Each is an autograd Function
+# over libs2g kernels; the layer composes them in the reference's order.
+# ----------------------------------------------------------------------------------------------------------------
+class AddLayerNormFn(torch.autograd.Function):
+    """y = LayerNorm(x + r * rmask) over the last dimension (rmask: the dropout multiplier of r, or None)."""
+
+    @staticmethod
+    def forward(ctx, x, r, rmask, gamma, beta, eps):
+        if not x.is_cuda:
+            raise S2GError("CustomTransformerEncoderLayer needs GPU tensors (MI355X-only implementation, no CPU path)")
+        E = x.shape[-1]
+        if E > 1024:
+            raise S2GError("the LayerNorm kernel takes up to 1024 features")
+        rows = x.numel() // E
+        xc, rc = x.contiguous().float(), r.contiguous().float()
+        mc = None if rmask is None else rmask.contiguous().float()
+        g, b = gamma.contiguous().float(), beta.contiguous().float()
+        y, xhat, rstd = torch.empty_like(xc), torch.empty_like(xc), torch.empty(rows, device=x.device)
+        call("s2g_add_layernorm_fwd", ptr(xc), ptr(rc), ptr(mc), ptr(g), ptr(b), float(eps), ptr(y), ptr(xhat), ptr(rstd),
+             rows, E, stream_ptr())
+        ctx.save_for_backward(xhat, rstd, g, mc)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        xhat, rstd, g, mc = ctx.saved_tensors
+        E = xhat.shape[-1]
+        rows = xhat.numel() // E
+        dy = dy.contiguous().float()
+        dz, dyxh = torch.empty_like(xhat), torch.empty_like(xhat)
+        call("s2g_add_layernorm_bwd", ptr(dy), ptr(xhat), ptr(rstd), ptr(g), ptr(dz), ptr(dyxh), rows, E, stream_ptr())
+        sc = ops.Scratch(dy.device)
+        dgamma, dbeta = torch.empty(E, device=dy.device), torch.empty(E, device=dy.device)
+        ops.colsum(dyxh, rows, E, E, dgamma, sc)
+        ops.colsum(dy, rows, E, E, dbeta, sc)
+        dr = dz
+        if mc is not None:
+            dr = dz.clone()
+            call("s2g_mul_inplace", ptr(dr), ptr(mc), dr.numel(), stream_ptr())
+        return dz, dr, None, dgamma, dbeta, None
+
+
+class LinearActFn(torch.autograd.Function):
+    """y = act(x W^T + b) over the last dimension; act 0: none, 2: ReLU (fused into the product's epilogue)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, act):
+        if not x.is_cuda:
+            raise S2GError("CustomTransformerEncoderLayer needs GPU tensors (MI355X-only implementation, no CPU path)")
+        K, N = x.shape[-1], W.shape[0]
+        M = x.numel() // K
+        xc, Wc, bc = x.contiguous().float().view(M, K), W.contiguous().float(), b.contiguous().float()
+        y = torch.empty(M, N, device=x.device)
+        ops.linear_fwd(xc, Wc, bc, y, act=act)
+        ctx.save_for_backward(xc, Wc, y)
+        ctx.act, ctx.lead = act, tuple(x.shape[:-1])
+        return y.view(*ctx.lead, N)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        xc, Wc, y = ctx.saved_tensors
+        M, K = xc.shape
+        N = Wc.shape[0]
+        dy = dy.contiguous().float().view(M, N)
+        if ctx.act == 2:
+            dy = dy.clone()
+            call("s2g_relu_bwd", ptr(y), ptr(dy), dy.numel(), stream_ptr())
+        sc = ops.Scratch(dy.device)
+        dx, dW, db = torch.empty(M, K, device=dy.device), torch.empty_like(Wc), torch.empty(N, device=dy.device)
+        ops.linear_bwd_dx(dy, Wc, dx, sc)
+        ops.linear_bwd_dw(dy, xc, dW, sc)
+        ops.colsum(dy, M, N, N, db, sc)
+        return dx.view(*ctx.lead, K), dW, db, None
+
+
+class MulMaskFn(torch.autograd.Function):
+    """y = x * mask (a dropout multiplier: 0 or 1 / (1 - p))."""
+
+    @staticmethod
+    def forward(ctx, x, mask):
+        y = x.contiguous().float().clone()
+        m = mask.contiguous().float()
+        call("s2g_mul_inplace", ptr(y), ptr(m), y.numel(), stream_ptr())
+        ctx.save_for_backward(m)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (m,) = ctx.saved_tensors
+        dx = dy.contiguous().float().clone()
+        call("s2g_mul_inplace", ptr(dx), ptr(m), dx.numel(), stream_ptr())
+        return dx, None
+
+
+def dropout_multiplier(shape, p: float, device, rng: ops.DeviceRng) -> Optional[torch.Tensor]:
+    """A train-mode dropout multiplier of the given shape drawn by the library's counter-based generator
+    (None for p = 0: nothing is dropped)."""
+    if p <= 0.0:
+        return None
+    width = shape[-1]
+    rows = 1
+    for d in shape[:-1]:
+        rows *= d
+    if width % 4:
+        raise S2GError("dropout multipliers are drawn four columns at a time: the last dimension must be a multiple of 4")
+    return ops.dropout_mask_rng(rows, p, device, rng, width=width, live=width).view(*shape)

@@ -107,6 +107,9 @@ SIGNATURES = {
     "s2g_embed_mul": [P, P, P, P, I, I, I, P],
     "s2g_embed_mul_bwd": [P, P, P, P, I, I, I, P],
     "s2g_lrelu_bwd": [P, P, L, P],
+    "s2g_relu_bwd": [P, P, L, P],
+    "s2g_add_layernorm_fwd": [P, P, P, P, P, F, P, P, P, L, I, P],
+    "s2g_add_layernorm_bwd": [P, P, P, P, P, P, L, I, P],
     "s2g_dropout_mask": [P, L, F, P],
     "s2g_bn_stats": [P, P, I, I, P],
     "s2g_bn_lrelu_apply": [P, P, F, P, P, P, P, F, F, I, P, P, P, I, I, P],

@@ -656,6 +656,60 @@ def g15_wgan_modules(ref):
     save("g15_wgan_modules.pt", out)
 
 
+def g16_encoder_layer(ref):
+    """CustomTransformerEncoderLayer (transformer.py:285-317) of the imported reference with dropout 0: the layer
+    alone (batch_first False and True) with the reference's causal and padding masks -- output and the gradients
+    of the input and of every parameter the forward uses -- and nn.TransformerEncoder stacking two of them in
+    train mode, as the reference's own self-test does (:340-348)."""
+    import transformer as T_ref
+    assert T_ref.__file__.startswith("/root/reference")
+    out = {}
+    N, T, E, H, DFF = 4, 24, 64, 4, 128
+    g = common.gen(1601)
+    used = ("attn.in_proj_weight", "attn.in_proj_bias", "attn.fc_out.weight", "attn.fc_out.bias", "linear1.weight",
+            "linear1.bias", "linear2.weight", "linear2.bias", "norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias")
+    for mode in ("plain", "batch_first"):
+        torch.manual_seed(1602)
+        layer = T_ref.CustomTransformerEncoderLayer(E, H, DFF, dropout=0.0, batch_first=(mode == "batch_first"))
+        with torch.no_grad():      # biases and LayerNorm parameters away from their 0 / 1 initial values
+            for n, q in layer.named_parameters():
+                if n.endswith("bias") or n.startswith("norm"):
+                    q.add_(0.2 * torch.randn(q.shape, generator=g))
+        layer.train()
+        x = torch.randn((N, T, E), generator=g)
+        tokens = torch.randint(0, 4, (N, T), generator=g)
+        dy = torch.randn((N, T, E), generator=g)
+        am, pm = T_ref.create_causal_mask(T), T_ref.create_padding_mask(tokens)
+        xin = x.clone().requires_grad_(True)
+        # in both modes dim 0 of the input is what the attention module treats as the batch: with batch_first the
+        # layer's transpose (:299-300) and the attention module's own (:223-226) cancel
+        y = layer(xin, src_mask=am, src_key_padding_mask=pm)
+        params = dict(layer.named_parameters())
+        grads = torch.autograd.grad(y, [xin] + [params[n] for n in used], dy)
+        out[f"{mode}.state"] = {k: v.clone() for k, v in layer.state_dict().items()}
+        out[f"{mode}.x"], out[f"{mode}.tokens"], out[f"{mode}.dy"] = x, tokens, dy
+        out[f"{mode}.y"] = y.detach().clone()
+        out[f"{mode}.dx"] = grads[0].clone()
+        for n, gv in zip(used, grads[1:]):
+            out[f"{mode}.grad.{n}"] = gv.clone()
+    # the reference's self-test arrangement: nn.TransformerEncoder over two layers, train mode
+    torch.manual_seed(1603)
+    layer = T_ref.CustomTransformerEncoderLayer(E, H, DFF, dropout=0.0, batch_first=False)
+    enc = torch.nn.TransformerEncoder(layer, num_layers=2)
+    enc.train()
+    x = torch.randn((N, T, E), generator=g)
+    tokens = torch.randint(0, 4, (N, T), generator=g)
+    dy = torch.randn((N, T, E), generator=g)
+    xin = x.clone().requires_grad_(True)
+    y = enc(xin, mask=T_ref.create_causal_mask(T), src_key_padding_mask=T_ref.create_padding_mask(tokens))
+    (dx,) = torch.autograd.grad(y, [xin], dy)
+    out["stack.state"] = {k: v.clone() for k, v in enc.state_dict().items()}
+    out["stack.x"], out["stack.tokens"], out["stack.dy"] = x, tokens, dy
+    out["stack.y"], out["stack.dx"] = y.detach().clone(), dx.clone()
+    print("g16: |y|", float(out["plain.y"].norm()), float(out["batch_first.y"].norm()), float(out["stack.y"].norm()))
+    save("g16_encoder_layer.pt", out)
+
+
 def g13_graph_encoder(ref):
     """GraphEncoder.encode (graph_encoder.py:57-133) on the sequences of common.graph_sequences with one encoder
     (its vocabulary grows across calls), plus the float64 centralities from the same networkx calls the reference
@@ -721,7 +775,7 @@ def main():
     a = ap.parse_args()
     torch.manual_seed(0)
     ref = import_reference()
-    todo = [g1_sampler, g2_generator, g3_critic, g4_gp, g5_ce, g6_adam, g7_full_step, g10_generate_fake_data, g11_attention, g12_wgan_clip, g13_graph_encoder, g15_wgan_modules]
+    todo = [g1_sampler, g2_generator, g3_critic, g4_gp, g5_ce, g6_adam, g7_full_step, g10_generate_fake_data, g11_attention, g12_wgan_clip, g13_graph_encoder, g15_wgan_modules, g16_encoder_layer]
     if a.full:
         todo += [g8_full_size, g9_full_step_full_size, g14_wgan_clip_full_size]
     for fn in todo:

@@ -35,3 +35,21 @@ def test_oracle_matches_reference_golden(golden, tag, mode):
     assert_close(y, G[f"{key}.y"], 1e-5, "y")
     for n, gv in zip(("dq", "dk", "dv", "d_in_w", "d_in_b", "d_out_w", "d_out_b"), grads):
         assert_close(gv, G[f"{key}.{n}"], 1e-4, n, atol=1e-7)
+
+
+def test_encoder_layer_restatement_matches_reference_golden(golden):
+    """oracle.attention_cpu.encoder_layer_forward against the imported reference's CustomTransformerEncoderLayer
+    (g16, dropout 0): output and input gradient, in float64."""
+    import torch
+    from oracle.attention_cpu import encoder_layer_forward
+    G = golden("g16_encoder_layer.pt")
+    T_ = 24
+    for mode in ("plain", "batch_first"):
+        p = {k: v.double() for k, v in G[f"{mode}.state"].items()}
+        x = G[f"{mode}.x"].double().requires_grad_(True)
+        am = torch.tril(torch.ones(T_, T_, dtype=torch.float64), diagonal=1)
+        pm = (G[f"{mode}.tokens"] == 0).double()
+        y = encoder_layer_forward(x, p, 4, am, pm)
+        (dx,) = torch.autograd.grad(y, [x], G[f"{mode}.dy"].double())
+        assert float((y - G[f"{mode}.y"].double()).abs().max()) < 1e-5
+        assert float((dx - G[f"{mode}.dx"].double()).abs().max()) < 1e-5

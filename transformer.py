@@ -1,5 +1,6 @@
 """MI355X-native attention with the module surface of the reference's transformer.py: the mask helpers,
-PositionalEncoding and MaskedMultiheadAttention (reference transformer.py:9-64, 196-282) -- same names,
+PositionalEncoding, MaskedMultiheadAttention and CustomTransformerEncoderLayer (reference transformer.py:9-64,
+196-317) -- same names,
 constructor arguments, parameter names (in_proj_weight [3E, 3E], in_proj_bias, fc_out.*) and conventions,
 including the unusual ones (the fused projection of concat(q, k, v), the finite -1e3 fill, the
 tril(diagonal=1) "causal" mask, scaling by sqrt(embed_size), the padding mask that fills the non-pad keys,
@@ -16,7 +17,8 @@ _PKG = os.path.join(os.path.dirname(os.path.abspath(__file__)), "sequence-to-gra
 if _PKG not in sys.path:
     sys.path.insert(0, _PKG)
 
-from s2g.attention import MultiheadAttentionFn  # noqa: E402
+from s2g import ops  # noqa: E402
+from s2g.attention import AddLayerNormFn, LinearActFn, MulMaskFn, MultiheadAttentionFn, dropout_multiplier  # noqa: E402
 
 
 def create_causal_mask(seq_len):
@@ -87,3 +89,57 @@ class MaskedMultiheadAttention(nn.Module):
         if self.batch_first:
             out = out.transpose(0, 1)
         return out
+
+
+class CustomTransformerEncoderLayer(nn.TransformerEncoderLayer):
+    """Reference :285-317: a subclass of nn.TransformerEncoderLayer (so nn.TransformerEncoder stacks it and the
+    state_dict keeps the parent's unused self_attn.* entries beside attn.*) whose forward is
+    src = norm1(src + dropout1(attn(src, src, src))); src = norm2(src + dropout2(linear2(dropout(relu(linear1(src)))))).
+    With batch_first the layer transposes its input AND the attention module transposes it back (:299-300 and
+    :223-226): kept.  Every product, the LayerNorms and the dropout multipliers are libs2g kernels; in train mode
+    the multipliers come from the library's counter-based generator (torch's dropout stream cannot be reproduced)."""
+
+    def __init__(self, embed_size, num_heads, dim_feedforward=2048, dropout=0.1, batch_first=False):
+        super(CustomTransformerEncoderLayer, self).__init__(embed_size, num_heads, dim_feedforward, dropout,
+                                                            batch_first=batch_first, activation=nn.functional.relu)
+        self.attn = MaskedMultiheadAttention(embed_size, num_heads, batch_first=batch_first)
+        self.linear1 = nn.Linear(embed_size, dim_feedforward)
+        self.dropout = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(dim_feedforward, embed_size)
+        self.norm1 = nn.LayerNorm(embed_size)
+        self.norm2 = nn.LayerNorm(embed_size)
+        self.dropout1 = nn.Dropout(dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        self.batch_first = batch_first
+        self.rng = None                 # ops.DeviceRng of the dropout multipliers (made on first use)
+        self.dropout_masks = None       # optional (mask1, mask_ffn, mask2) used instead of drawn multipliers
+
+    def _masks(self, src, dff):
+        if self.dropout_masks is not None:
+            return self.dropout_masks
+        if not self.training:
+            return None, None, None
+        if self.rng is None:
+            self.rng = ops.DeviceRng()
+        dev = src.device
+        return (dropout_multiplier(tuple(src.shape), self.dropout1.p, dev, self.rng),
+                dropout_multiplier(tuple(src.shape[:-1]) + (dff,), self.dropout.p, dev, self.rng),
+                dropout_multiplier(tuple(src.shape), self.dropout2.p, dev, self.rng))
+
+    def forward(self, src, src_mask=None, src_key_padding_mask=None, **kwargs):
+        if self.batch_first:
+            src = src.transpose(0, 1)
+        src = src.contiguous()
+        m1, mf, m2 = self._masks(src, self.linear1.out_features)
+        # self-attention block
+        src2 = self.attn(src, src, src, attn_mask=src_mask, src_key_padding_mask=src_key_padding_mask)
+        src = AddLayerNormFn.apply(src, src2, m1, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        # feed-forward block
+        h = LinearActFn.apply(src, self.linear1.weight, self.linear1.bias, 2)
+        if mf is not None:
+            h = MulMaskFn.apply(h, mf)
+        src2 = LinearActFn.apply(h, self.linear2.weight, self.linear2.bias, 0)
+        src = AddLayerNormFn.apply(src, src2, m2, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        if self.batch_first:
+            src = src.transpose(0, 1)
+        return src
