@@ -72,6 +72,8 @@ typedef struct S2GGemm {
   const float* bias;
   int M, N, K, kchunk, segT, a_seg, b_seg, shift, accumulate, act;
   float alpha;
+  const float* bscale;   /* grouped launches only, segT > 0: row k of B is multiplied by bscale[k / segT] (one factor
+                          * per sequence; NULL: none).  s2g_gemm_f32 ignores it. */
 } S2GGemm;
 int s2g_gemm_f32(const S2GGemm* args, int nsplit, void* stream);
 /* the tall products of the critic's input layer (x W_ih0^T, delta W_ih0, delta (W_ih0 W_ih0^T);
@@ -279,7 +281,8 @@ int s2g_gp_norm_penalty_proj(const float* delta, float* pv, int B, long per_samp
  * unscaled: partial[b][q] = sum over the q-th quarter of sample b of delta . pv; the tangent sweep
  * takes the coefficient from the partials, s2g_gp_penalty_final gives pen / norms (wgan_gp.py:255-256) */
 int s2g_gp_dots(const float* delta, const float* pv, int B, long per_sample, float* partial, void* stream);
-int s2g_gp_penalty_final(const float* partial, int B, float* pen, float* norms, void* stream);
+int s2g_gp_penalty_final(const float* partial, int B, float upstream, float n_batch, float* pen, float* norms,
+                         float* coef, void* stream);
 int s2g_gp_scale(const float* g, const float* norms, const float* upstream, float n_batch, long per_sample,
                  float* v, int B, void* stream);
 
@@ -419,6 +422,14 @@ int s2g_embed_grad_tokens(const int* tokens, const int* lengths, int T, long row
  * gradients of W_ih0 and of the embedding (both are products of these [V, 256] sums with small matrices). */
 int s2g_bucket_rows_by_token(const int* tokens, const int* lengths, int T, long rows, int V, const float* x, int ld,
                              int width, float* out, float* part, void* stream);
+/* The same bucketed sums for any width (the last 32-column slice may be partial) over rows laid out x_seg >= T rows
+ * per sequence (row of step t of sequence n = n * x_seg + t; tokens / lengths still count T per sequence), written
+ * TRANSPOSED: out[c * ldo + v] = sum over live rows with token v of x[row][c].  With x = the layer-0 gate gradients of
+ * sequences whose input is one-hot this is that weight gradient itself, dW_ih0[gate row][token] (the autograd of
+ * F.one_hot(...).float() through nn.LSTM, wgan_gp.py:277, 317), without a one-hot operand or a product with zeros.
+ * part: s2g_embed_grad_tokens_scratch(rows, V) * ceil(width / 32) floats. */
+int s2g_bucket_rows_by_token_t(const int* tokens, const int* lengths, int T, long rows, int V, const float* x, int ld,
+                               int x_seg, int width, float* out, int ldo, float* part, void* stream);
 /* out [n_classes, width] = sum over sequences with label l (ascending) of x[n] (x [B, width], width <= 1024) */
 int s2g_bucket_rows_by_label(const long long* labels, int B, int n_classes, const float* x, int width, float* out,
                              void* stream);

@@ -561,13 +561,15 @@ extern "C" __global__ __launch_bounds__(1024) void s2g_k_gp_dots(const float* __
     partial[b * 4 + q] = tot;
   }
 }
-extern "C" __global__ void s2g_k_gp_penalty_final(const float* __restrict__ partial, int B,
-                                                  float* __restrict__ pen, float* __restrict__ norms) {
+extern "C" __global__ void s2g_k_gp_penalty_final(const float* __restrict__ partial, int B, float upstream,
+                                                  float n_batch, float* __restrict__ pen, float* __restrict__ norms,
+                                                  float* __restrict__ coef) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const float nb = gp_norm_from_partials(partial + 4 * b);
   pen[b] = (nb - 1.0f) * (nb - 1.0f);
   if (norms) norms[b] = nb;
+  if (coef) coef[b] = gp_coef_from_partials(partial + 4 * b, upstream, n_batch);     // the factor sweep C applies
 }
 
 // v_b = coef_b * g_b with coef_b = upstream * 2 (n_b - 1) / (n_batch * n_b), out of place

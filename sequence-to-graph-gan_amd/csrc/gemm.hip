@@ -44,6 +44,7 @@ struct GemmArgs {
   const float* bias;
   int M, N, K, kchunk, segT, a_seg, b_seg, shift, accumulate, act;
   float alpha;
+  const float* bscale;      // grouped kernels, segT > 0: B's row k times bscale[k / segT] (per-sequence factor) or nullptr
 };
 
 // (sequence, step) position of a reduction index under the segT mapping, advanced incrementally so
@@ -291,23 +292,27 @@ __device__ __forceinline__ void wgrad_tile(const GemmArgs& g, const int bx, cons
   if (segT > 0) { rb = rk / segT; rt = rk - rb * segT; }
   const long shiftB = g.shift ? 1 : 0;
   const float *pa, *pb;
+  float bsc = 1.0f;                 // per-sequence factor on B's rows (wave-uniform; reloaded when the sequence changes)
+  const int nseq_k = segT > 0 ? (g.K + segT - 1) / segT : 1;
   auto rowptrs = [&]() {
     const long rowA = segT > 0 ? (long)rb * g.a_seg + rt : (long)rk;
     const long rowB = (segT > 0 ? (long)rb * g.b_seg + rt : (long)rk) - shiftB;
     pa = g.A + rowA * g.sak;
     pb = g.B + rowB * g.sbk;      // with shift at rt == 0 this is never dereferenced
+    if (g.bscale && segT > 0) bsc = g.bscale[min(rb, nseq_k - 1)];
   };
   rowptrs();
   const long stepA = 4 * g.sak, stepB = 4 * g.sbk;
 
   float4 ra[8];
-  float rbv[8];
+  float rbv[8], rsc[8];
   unsigned okA = 0, okB = 0;        // scalar masks: row e exists for A / B
   auto fetch = [&](int e) {         // row rk -> slot e, then step to row rk + 4
     const bool in = rk < kend;
     const bool inB = in && !(g.shift && rt == 0);
     ra[e] = gload4((in ? pa : g.A) + a_lane);
     rbv[e] = gload((inB ? pb : g.B) + b_lane);
+    rsc[e] = bsc;
     if (e == 0) { okA = 0; okB = 0; }
     okA |= in ? (1u << e) : 0u;
     okB |= inB ? (1u << e) : 0u;
@@ -327,7 +332,7 @@ __device__ __forceinline__ void wgrad_tile(const GemmArgs& g, const int bx, cons
       float4 v;
       v.x = la ? ra[e].x : 0.0f; v.y = la ? ra[e].y : 0.0f; v.z = la ? ra[e].z : 0.0f; v.w = la ? ra[e].w : 0.0f;
       *reinterpret_cast<float4*>(As + kr * WLD_A + 4 * lane) = v;
-      Bs[kr * WLD_B + lane] = lb ? rbv[e] : 0.0f;
+      Bs[kr * WLD_B + lane] = lb ? rbv[e] * rsc[e] : 0.0f;
     }
   };
 

@@ -143,11 +143,14 @@ __device__ __forceinline__ void wgrad_tile_bf16(const GemmArgs& g, const int bx,
   if (segT > 0) { rb = rk / segT; rt = rk - rb * segT; }
   const long shiftB = g.shift ? 1 : 0;
   const float *pa, *pb;
+  float bsc = 1.0f;                   // per-sequence factor on B's rows (wave-uniform; reloaded when the sequence changes)
+  const int nseq_k = segT > 0 ? (g.K + segT - 1) / segT : 1;
   auto rowptrs = [&]() {
     const long rowA = segT > 0 ? (long)rb * g.a_seg + rt : (long)rk;
     const long rowB = (segT > 0 ? (long)rb * g.b_seg + rt : (long)rk) - shiftB;
     pa = g.A + rowA * g.sak;
     pb = g.B + rowB * g.sbk;          // with shift at rt == 0 this is never dereferenced
+    if (g.bscale && segT > 0) bsc = g.bscale[min(rb, nseq_k - 1)];
   };
   rowptrs();
   auto advance = [&](int d) {
@@ -161,13 +164,14 @@ __device__ __forceinline__ void wgrad_tile_bf16(const GemmArgs& g, const int bx,
   };
 
   float4 ra[8];
-  float rbv[8];
+  float rbv[8], rsc[8];
   unsigned okA = 0, okB = 0;          // scalar masks: row j exists for A / B
   auto fetch = [&](int j) {           // row rk -> slot j, then on to the next row of this wave
     const bool in = rk < kend;
     const bool inB = in && !(g.shift && rt == 0);
     ra[j] = gload4((in ? pa : g.A) + a_lane);
     rbv[j] = gload((inB ? pb : g.B) + b_lane);
+    rsc[j] = bsc;
     if (j == 0) { okA = 0; okB = 0; }
     okA |= in ? (1u << j) : 0u;
     okB |= inB ? (1u << j) : 0u;
@@ -182,7 +186,7 @@ __device__ __forceinline__ void wgrad_tile_bf16(const GemmArgs& g, const int bx,
       const bool la = a_in && ((okA >> j) & 1u), lb = b_in && ((okB >> j) & 1u);
       va[0][j] = la ? ra[j].x : 0.0f; va[1][j] = la ? ra[j].y : 0.0f;
       va[2][j] = la ? ra[j].z : 0.0f; va[3][j] = la ? ra[j].w : 0.0f;
-      vb[j] = lb ? rbv[j] : 0.0f;
+      vb[j] = lb ? rbv[j] * rsc[j] : 0.0f;
     }
     if (lane < GB_MT * 4) {
 #pragma unroll

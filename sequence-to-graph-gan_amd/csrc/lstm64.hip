@@ -595,10 +595,13 @@ extern "C" __global__ void s2g_k_embed_concat(const int* __restrict__ tokens, co
 #define EG_BATCH 32
 extern "C" __global__ __launch_bounds__(32 * EG_GROUPS) void s2g_k_embed_grad_tokens_part(
     const int* __restrict__ tokens, const int* __restrict__ lengths, int T, long rows, int V,
-    const float* __restrict__ dx, int ld, int chunk, float* __restrict__ part) {
-  // blockIdx.y: a slice of 32 columns of dx (row stride ld); part [chunk][slice][V * 32]
+    const float* __restrict__ dx, int ld, int chunk, float* __restrict__ part, int width, int x_seg) {
+  // blockIdx.y: a slice of 32 columns of dx (row stride ld); part [chunk][slice][V * 32].
+  // width: live columns of dx (the last slice may be partial: its dead columns re-read the last live one and are
+  // dropped by the final stage); x_seg: rows a sequence owns in dx (>= T; tokens and lengths count T per sequence).
   extern __shared__ float eg_tab[];      // [EG_GROUPS][V * 32]
-  const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int g = threadIdx.x >> 5;
+  const int c = min((int)(threadIdx.x & 31), width - 1 - 32 * (int)blockIdx.y);
   dx += blockIdx.y * 32;
   const int n = V * 32;
   for (int i = threadIdx.x; i < EG_GROUPS * n; i += 32 * EG_GROUPS) eg_tab[i] = 0.0f;
@@ -620,9 +623,10 @@ extern "C" __global__ __launch_bounds__(32 * EG_GROUPS) void s2g_k_embed_grad_to
       // every load unconditional (a load in the arm of a select or behind && becomes a branch, and the join
       // waits for all loads in flight: one memory round trip per row)
       const long r = min(rb + k, rows - 1);
-      const int len = lengths[min(sq, nseq - 1)];
+      const int sqc = min(sq, nseq - 1);
+      const int len = min(max(lengths[sqc], 0), T);
       const int tv = tokens[r];
-      v[k] = dx[r * ld + c];
+      v[k] = dx[((long)sqc * x_seg + st) * ld + c];
       const bool live = (rb + k < r1) & (st < len);
       tk[k] = live ? min(max(tv, 0), V - 1) : -1;
       const bool wrap = st + 1 == T;
@@ -631,7 +635,7 @@ extern "C" __global__ __launch_bounds__(32 * EG_GROUPS) void s2g_k_embed_grad_to
     }
 #pragma unroll
     for (int k = 0; k < EG_BATCH; ++k)
-      if (tk[k] >= 0) tab[tk[k] * 32 + c] += v[k];
+      if (tk[k] >= 0) tab[tk[k] * 32 + (threadIdx.x & 31)] += v[k];
   }
   __syncthreads();
   float* out = part + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * n;
@@ -659,6 +663,27 @@ extern "C" __global__ __launch_bounds__(256) void s2g_k_embed_grad_final(const f
   const float s = (s0 + s1) + (s2 + s3);
   float* o = out + (size_t)(i >> 5) * ldo + sl * 32 + (i & 31);
   *o = accumulate ? *o + s : s;
+}
+
+// the same final stage written TRANSPOSED: out[(sl * 32 + c) * ldo + v] for columns below `width` (the bucketed sums
+// of gate gradients enter a weight gradient stored [gate row][token])
+extern "C" __global__ __launch_bounds__(256) void s2g_k_embed_grad_final_t(const float* __restrict__ part, int nchunks,
+                                                                           int n, int width, float* __restrict__ out,
+                                                                           int ldo) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int nsl = gridDim.y, sl = blockIdx.y;
+  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+  int k = 0;
+  for (; k + 3 < nchunks; k += 4) {
+    s0 += part[((size_t)k * nsl + sl) * n + i];
+    s1 += part[((size_t)(k + 1) * nsl + sl) * n + i];
+    s2 += part[((size_t)(k + 2) * nsl + sl) * n + i];
+    s3 += part[((size_t)(k + 3) * nsl + sl) * n + i];
+  }
+  for (; k < nchunks; ++k) s0 += part[((size_t)k * nsl + sl) * n + i];
+  const int col = sl * 32 + (i & 31);
+  if (col < width) out[(size_t)col * ldo + (i >> 5)] = (s0 + s1) + (s2 + s3);
 }
 
 // out[l][c] = sum over sequences n with label l (ascending) of x[n][c]; one workgroup per class, thread = column

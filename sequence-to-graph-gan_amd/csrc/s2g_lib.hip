@@ -352,9 +352,11 @@ int s2g_gp_dots(const float* delta, const float* pv, int B, long per_sample, flo
   hipLaunchKernelGGL(s2g_k_gp_dots, dim3(B, 4), dim3(1024), 0, ST(stream), delta, pv, per_sample, partial);
   return LAUNCH_OK();
 }
-int s2g_gp_penalty_final(const float* partial, int B, float* pen, float* norms, void* stream) {
-  if (!partial || !pen || B <= 0) return -1;
-  hipLaunchKernelGGL(s2g_k_gp_penalty_final, dim3(cdiv(B, 64)), dim3(64), 0, ST(stream), partial, B, pen, norms);
+int s2g_gp_penalty_final(const float* partial, int B, float upstream, float n_batch, float* pen, float* norms,
+                         float* coef, void* stream) {
+  if (!partial || !pen || B <= 0 || (coef && !(n_batch > 0.0f))) return -1;
+  hipLaunchKernelGGL(s2g_k_gp_penalty_final, dim3(cdiv(B, 64)), dim3(64), 0, ST(stream), partial, B, upstream, n_batch,
+                     pen, norms, coef);
   return LAUNCH_OK();
 }
 
@@ -631,7 +633,8 @@ long s2g_embed_grad_tokens_scratch(long rows, int V) {
   return ((rows + EG_CHUNK - 1) / EG_CHUNK) * (long)V * 32;
 }
 static int bucket_rows_by_token(const int* tokens, const int* lengths, int T, long rows, int V, const float* x, int ld,
-                                int width, float* out, int ldo, int accumulate, float* part, void* stream);
+                                int width, float* out, int ldo, int accumulate, float* part, void* stream,
+                                int x_seg = 0, int transposed = 0);
 int s2g_embed_grad_tokens(const int* tokens, const int* lengths, int T, long rows, int V, const float* dx, float* demb,
                           int accumulate, float* part, void* stream) {
   return bucket_rows_by_token(tokens, lengths, T, rows, V, dx, 64, 32, demb, 32, accumulate, part, stream);
@@ -640,6 +643,11 @@ int s2g_bucket_rows_by_token(const int* tokens, const int* lengths, int T, long 
                              int width, float* out, float* part, void* stream) {
   return bucket_rows_by_token(tokens, lengths, T, rows, V, x, ld, width, out, width, 0, part, stream);
 }
+int s2g_bucket_rows_by_token_t(const int* tokens, const int* lengths, int T, long rows, int V, const float* x, int ld,
+                               int x_seg, int width, float* out, int ldo, float* part, void* stream) {
+  if (x_seg < T || ldo < V) return -1;
+  return bucket_rows_by_token(tokens, lengths, T, rows, V, x, ld, width, out, ldo, 0, part, stream, x_seg, 1);
+}
 int s2g_bucket_rows_by_label(const long long* labels, int B, int n_classes, const float* x, int width, float* out,
                              void* stream) {
   if (!labels || !x || !out || B <= 0 || n_classes <= 0 || width <= 0 || width > 1024) return -1;
@@ -647,24 +655,30 @@ int s2g_bucket_rows_by_label(const long long* labels, int B, int n_classes, cons
   return LAUNCH_OK();
 }
 static int bucket_rows_by_token(const int* tokens, const int* lengths, int T, long rows, int V, const float* dx, int ld,
-                                int width, float* demb, int ldo, int accumulate, float* part, void* stream) {
+                                int width, float* demb, int ldo, int accumulate, float* part, void* stream, int x_seg,
+                                int transposed) {
   if (!tokens || !lengths || !dx || !demb || !part || T <= 0 || rows <= 0 || V <= 0) return -1;
   if (rows % T) return -1;                                         // rows = sequences x T: lengths[] is read per sequence
-  if (width <= 0 || width % 32 || ld < width || ldo < width) return -1;
+  if (width <= 0 || ld < width || (!transposed && (width % 32 || ldo < width))) return -1;
+  if (x_seg <= 0) x_seg = T;
   const size_t lds = (size_t)EG_GROUPS * V * 32 * sizeof(float);   // four tables of V x 32 floats in LDS
   if (lds > 160 * 1024) return -1;                                 // V <= 320
   static S2GLdsCap lds_cap;
   if (s2g_lds_cap(lds_cap, (const void*)s2g_k_embed_grad_tokens_part, 160 * 1024) != 0) return -2;
-  const int nsl = width / 32;
+  const int nsl = (width + 31) / 32;
   // rows per workgroup: about one workgroup per CU over all column slices (a workgroup zeroes and flushes whole
   // tables, so short chunks of wide matrices are all overhead); never below EG_CHUNK, the unit the scratch is sized by
   long chunk = ((rows * nsl / 256 + EG_CHUNK - 1) / EG_CHUNK) * EG_CHUNK;
   chunk = chunk < EG_CHUNK ? EG_CHUNK : (chunk > 16 * EG_CHUNK ? 16 * EG_CHUNK : chunk);
   const int nchunks = (int)((rows + chunk - 1) / chunk);
   hipLaunchKernelGGL(s2g_k_embed_grad_tokens_part, dim3(nchunks, nsl), dim3(32 * EG_GROUPS), lds, ST(stream), tokens,
-                     lengths, T, rows, V, dx, ld, (int)chunk, part);
-  hipLaunchKernelGGL(s2g_k_embed_grad_final, dim3(cdiv((long)V * 32, 256), nsl), dim3(256), 0, ST(stream), part, nchunks,
-                     V * 32, demb, ldo, accumulate);
+                     lengths, T, rows, V, dx, ld, (int)chunk, part, width, x_seg);
+  if (transposed)
+    hipLaunchKernelGGL(s2g_k_embed_grad_final_t, dim3(cdiv((long)V * 32, 256), nsl), dim3(256), 0, ST(stream), part,
+                       nchunks, V * 32, width, demb, ldo);
+  else
+    hipLaunchKernelGGL(s2g_k_embed_grad_final, dim3(cdiv((long)V * 32, 256), nsl), dim3(256), 0, ST(stream), part,
+                       nchunks, V * 32, demb, ldo, accumulate);
   return LAUNCH_OK();
 }
 int s2g_embed_grad_labels(const long long* labels, const int* lengths, int T, int B, int n_classes, const float* dx,

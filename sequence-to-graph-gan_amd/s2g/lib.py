@@ -26,7 +26,7 @@ class S2GSeq(ctypes.Structure):
 class S2GGemm(ctypes.Structure):
     _fields_ = [("A", P), ("sam", L), ("sak", L), ("B", P), ("sbk", L), ("sbn", L), ("C", P), ("ldc", L),
                 ("slab", L), ("bias", P), ("M", I), ("N", I), ("K", I), ("kchunk", I), ("segT", I),
-                ("a_seg", I), ("b_seg", I), ("shift", I), ("accumulate", I), ("act", I), ("alpha", F)]
+                ("a_seg", I), ("b_seg", I), ("shift", I), ("accumulate", I), ("act", I), ("alpha", F), ("bscale", P)]
 
 
 class S2GHead(ctypes.Structure):
@@ -102,7 +102,7 @@ SIGNATURES = {
     "s2g_gp_norm_penalty": [P, I, L, F, F, P, P, I, P],
     "s2g_gp_norm_penalty_proj": [P, P, I, L, F, F, P, P, P],
     "s2g_gp_dots": [P, P, I, L, P, P],
-    "s2g_gp_penalty_final": [P, I, P, P, P],
+    "s2g_gp_penalty_final": [P, I, F, F, P, P, P, P],
     "s2g_gp_scale": [P, P, P, F, L, P, I, P],
     "s2g_embed_mul": [P, P, P, P, I, I, I, P],
     "s2g_embed_mul_bwd": [P, P, P, P, I, I, I, P],
@@ -127,6 +127,7 @@ SIGNATURES = {
     "s2g_embed_grad_tokens": [P, P, I, L, I, P, P, I, P, P],
     "s2g_embed_grad_labels": [P, P, I, I, I, P, P, I, P, P],
     "s2g_bucket_rows_by_token": [P, P, I, L, I, P, I, I, P, P, P],
+    "s2g_bucket_rows_by_token_t": [P, P, I, L, I, P, I, I, I, P, I, P, P],
     "s2g_bucket_rows_by_label": [P, I, I, P, I, P, P],
     "s2g_attnpool_fwd": [P, P, P, P, P, I, I, I, P, P, P, P],
     "s2g_attnpool_bwd": [P, P, P, P, P, P, I, I, I, P, P, P, P, P],

@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts():
     from s2g import lib
     assert ctypes.sizeof(lib.S2GSeq) == 32
-    assert lib.S2GGemm.alpha.offset == 80 + 10 * 4 and ctypes.sizeof(lib.S2GGemm) == 128
+    assert lib.S2GGemm.alpha.offset == 80 + 10 * 4 and lib.S2GGemm.bscale.offset == 128 and ctypes.sizeof(lib.S2GGemm) == 136
     from s2g.critic import make_desc
     d = make_desc([dict(len=7, tok_off=3, p_off=5, p_len=9, ca=0.25, cp=0.75, mask_off=11, ws_row=13)], "cpu")
     raw = (ctypes.c_int * 8)(*d[0].tolist())

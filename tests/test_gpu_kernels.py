@@ -150,7 +150,7 @@ def test_gp_norm_penalty_proj_matches_formula():
     part = torch.empty(B, 4, device=DEV)
     pen2, norms2 = torch.empty(B, device=DEV), torch.empty(B, device=DEV)
     call("s2g_gp_dots", ptr(delta), ptr(pv0), B, T * 200, ptr(part), stream_ptr())
-    call("s2g_gp_penalty_final", ptr(part), B, ptr(pen2), ptr(norms2), stream_ptr())
+    call("s2g_gp_penalty_final", ptr(part), B, 0.0, 1.0, ptr(pen2), ptr(norms2), None, stream_ptr())
     torch.cuda.synchronize()
     assert rel(part.double().sum(1).cpu(), n ** 2) < TOL
     assert rel(norms2.cpu(), n) < TOL

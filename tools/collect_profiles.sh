@@ -1,5 +1,5 @@
 set -e
-TAG=${1:-r02_m}
+TAG=${1:-r03_b}
 R=/root/repo; O=$R/gpurun_out/final; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 timeout -k 10 600 python -u -m pytest $R/tests -m gpu -x -q --timeout 120 --timeout-method thread -p no:cacheprovider > $O/gputests.log 2>&1
