@@ -407,8 +407,10 @@ def main():
             "s2g_k_lstm2_bwd": rows3 * SWEEP_FLOP_PER_STEP,
             "s2g_k_lstm2_tangent": real * SWEEP_FLOP_PER_STEP,
             "s2g_k_lstm2_bwd2": real * SWEEP_FLOP_PER_STEP,
-            # dW_ih0: 4 products of [200 x rows] x [rows x V]; dW_hh0, dW_ih1, dW_hh1: 4 row-blocks x [200 x 50]
-            "s2g_k_gemm_grouped": 2.0 * 200 * (V * (3 * real + fake_steps) + 3 * 50 * (3 * real + fake_steps)),
+            # dW_ih0: the fake third's and the x_hat product [200 x rows] x [rows x V] and the 200-wide Gram product of
+            # the penalty's first-order factor (the real third is a bucketed sum, not a product);
+            # dW_hh0, dW_ih1, dW_hh1: 4 row-blocks x [200 x 50] each
+            "s2g_k_gemm_grouped": 2.0 * 200 * (V * (real + fake_steps) + 200 * real + 3 * 50 * (3 * real + fake_steps)),
         }
         # "name#phase" entries are the launches of one kernel inside one critic iteration (the grouped
         # GEMM runs as three launches, one per phase): their average durations add up to the kernel's

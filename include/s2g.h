@@ -138,6 +138,11 @@ int s2g_gemm_grouped_bf16(const S2GGemm* table_dev, const int* prefix_dev, int n
                           void* stream);
 int s2g_reduce_slabs(const float* slabs, long slab, int nslab, int rows, int cols, float* out,
                      int permute_rows, int accumulate, float scale, void* stream);
+/* out[i] = sum_z weights[z] * slabs[z * slab + i] (ascending z, i < n <= slab): with one split-K slab per sequence, a
+ * per-sequence weighted sum of outer products (the first-order factor of the penalty's weight gradient, autograd of
+ * wgan_gp.py:247-256) gets its weights after the product has run. */
+int s2g_reduce_slabs_weighted(const float* slabs, long slab, int nslab, const float* weights, float* out, long n,
+                              void* stream);
 /* up to 8 such reductions in one launch; `jobs` is a HOST array (copied into the kernel arguments) */
 typedef struct S2GReduce {
   const float* slabs; long slab; float* out;

@@ -270,6 +270,11 @@ __global__ __launch_bounds__(256) void s2g_k_gemm_f32(GemmArgs g) {
 #define WG_MT 13     // 16-row tiles: M <= 208
 #define WLD_A 272   // k-major A tile [BK][256 + 16]: = 16 mod 64 floats, conflict-free 16x4 fragment reads
 #define WLD_B 80    // k-major B tile [BK][64 + 16]
+// SCALED: B's row k is multiplied by bscale[sequence of k] (a per-sequence factor, segT > 0).  The factor travels
+// with the row as one more VECTOR load from a wave-uniform address: a scalar load would be counted in lgkmcnt, and
+// the wait for it would also wait for every LDS fragment read in flight.  A template parameter, so that the
+// products without factors keep their exact instruction stream.
+template <bool SCALED>
 __device__ __forceinline__ void wgrad_tile(const GemmArgs& g, const int bx, const int bz, float* As, float* Bs) {
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -292,14 +297,12 @@ __device__ __forceinline__ void wgrad_tile(const GemmArgs& g, const int bx, cons
   if (segT > 0) { rb = rk / segT; rt = rk - rb * segT; }
   const long shiftB = g.shift ? 1 : 0;
   const float *pa, *pb;
-  float bsc = 1.0f;                 // per-sequence factor on B's rows (wave-uniform; reloaded when the sequence changes)
   const int nseq_k = segT > 0 ? (g.K + segT - 1) / segT : 1;
   auto rowptrs = [&]() {
     const long rowA = segT > 0 ? (long)rb * g.a_seg + rt : (long)rk;
     const long rowB = (segT > 0 ? (long)rb * g.b_seg + rt : (long)rk) - shiftB;
     pa = g.A + rowA * g.sak;
     pb = g.B + rowB * g.sbk;      // with shift at rt == 0 this is never dereferenced
-    if (g.bscale && segT > 0) bsc = g.bscale[min(rb, nseq_k - 1)];
   };
   rowptrs();
   const long stepA = 4 * g.sak, stepB = 4 * g.sbk;
@@ -312,7 +315,7 @@ __device__ __forceinline__ void wgrad_tile(const GemmArgs& g, const int bx, cons
     const bool inB = in && !(g.shift && rt == 0);
     ra[e] = gload4((in ? pa : g.A) + a_lane);
     rbv[e] = gload((inB ? pb : g.B) + b_lane);
-    rsc[e] = bsc;
+    if (SCALED) rsc[e] = gload(g.bscale + min(rb, nseq_k - 1));
     if (e == 0) { okA = 0; okB = 0; }
     okA |= in ? (1u << e) : 0u;
     okB |= inB ? (1u << e) : 0u;
@@ -332,7 +335,7 @@ __device__ __forceinline__ void wgrad_tile(const GemmArgs& g, const int bx, cons
       float4 v;
       v.x = la ? ra[e].x : 0.0f; v.y = la ? ra[e].y : 0.0f; v.z = la ? ra[e].z : 0.0f; v.w = la ? ra[e].w : 0.0f;
       *reinterpret_cast<float4*>(As + kr * WLD_A + 4 * lane) = v;
-      Bs[kr * WLD_B + lane] = lb ? rbv[e] * rsc[e] : 0.0f;
+      Bs[kr * WLD_B + lane] = lb ? (SCALED ? rbv[e] * rsc[e] : rbv[e]) : 0.0f;
     }
   };
 
@@ -432,7 +435,8 @@ extern "C" __global__ __launch_bounds__(256) void s2g_k_gemm_grouped(const GemmA
     const int bz = lid / tiles, t = lid - bz * tiles;
     while (p + 1 < nprob && t >= prefix[p + 1]) ++p;
     const GemmArgs gs = table[p];
-    wgrad_tile(gs, t - prefix[p], bz, As, Bs);
+    if (gs.bscale != nullptr && gs.segT > 0) wgrad_tile<true>(gs, t - prefix[p], bz, As, Bs);
+    else wgrad_tile<false>(gs, t - prefix[p], bz, As, Bs);
     return;
   }
   while (p + 1 < nprob && lid >= prefix[p + 1]) ++p;
@@ -440,7 +444,8 @@ extern "C" __global__ __launch_bounds__(256) void s2g_k_gemm_grouped(const GemmA
   const int local = lid - prefix[p];
   const int nx = (gs.N + BN - 1) / BN;
   const int bx = local % nx, bz = local / nx;
-  wgrad_tile(gs, bx, bz, As, Bs);
+  if (gs.bscale != nullptr && gs.segT > 0) wgrad_tile<true>(gs, bx, bz, As, Bs);
+  else wgrad_tile<false>(gs, bx, bz, As, Bs);
 }
 
 // out[perm(r)][c] (+)= scale * sum_z slabs[z][r][c];   perm = internal gate row -> torch row when
@@ -479,6 +484,26 @@ extern "C" __global__ __launch_bounds__(256) void s2g_k_reduce_slabs(const float
                                                                      float* __restrict__ out, int permute_rows,
                                                                      int accumulate, float scale) {
   reduce_slabs_block(slabs, slab, nslab, rows, cols, out, permute_rows, accumulate, scale, blockIdx.x);
+}
+
+// out[i] = sum_z w[z] * slabs[z][i] (ascending z, i < n): a weighted slab sum.  With one slab per sequence (K-chunk =
+// a sequence's rows) the factor of a per-sequence weighted sum of outer products is applied here, after the
+// product, so the product itself can run before the weights are known.
+extern "C" __global__ __launch_bounds__(256) void s2g_k_reduce_slabs_weighted(const float* __restrict__ slabs, long slab,
+                                                                              int nslab, const float* __restrict__ w,
+                                                                              float* __restrict__ out, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+  int z = 0;
+  for (; z + 3 < nslab; z += 4) {       // four slabs' loads in flight; one fixed order of additions
+    s0 = fmaf(w[z], slabs[(long)z * slab + i], s0);
+    s1 = fmaf(w[z + 1], slabs[(long)(z + 1) * slab + i], s1);
+    s2 = fmaf(w[z + 2], slabs[(long)(z + 2) * slab + i], s2);
+    s3 = fmaf(w[z + 3], slabs[(long)(z + 3) * slab + i], s3);
+  }
+  for (; z < nslab; ++z) s0 = fmaf(w[z], slabs[(long)z * slab + i], s0);
+  out[i] = (s0 + s1) + (s2 + s3);
 }
 
 // Several independent reductions in one launch (the four weight gradients of a critic iteration):
@@ -1142,6 +1167,13 @@ extern "C" int s2g_launch_gemm(const GemmArgs* ga, int nsplit, hipStream_t strea
 extern "C" int s2g_launch_gemm_grouped(const GemmArgs* table_dev, const int* prefix_dev, int nprob, int total_blocks,
                                        int nz, hipStream_t stream) {
   hipLaunchKernelGGL(s2g_k_gemm_grouped, dim3(total_blocks), dim3(256), 0, stream, table_dev, prefix_dev, nprob, nz);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int s2g_launch_reduce_slabs_weighted(const float* slabs, long slab, int nslab, const float* w, float* out,
+                                               long n, hipStream_t stream) {
+  hipLaunchKernelGGL(s2g_k_reduce_slabs_weighted, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, slabs, slab,
+                     nslab, w, out, n);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -124,6 +124,7 @@ extern "C" int s2g_launch_gemm_tall_bf16(const float* A, long lda, const float* 
 // spreads the fragment READS of 16 consecutive m over all 64 banks (the writes of A take a 4-way conflict: all
 // lanes of an instruction share m mod 4).  With 1/16 of the fp32 matrix time the kernel is bound by its loads.
 #define GB_MT 13                     // 16-row tiles: M <= 208
+template <bool SCALED>              // per-sequence factor on B's rows, as in wgrad_tile
 __device__ __forceinline__ void wgrad_tile_bf16(const GemmArgs& g, const int bx, const int bz, __bf16* At, __bf16* Bt) {
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -143,14 +144,12 @@ __device__ __forceinline__ void wgrad_tile_bf16(const GemmArgs& g, const int bx,
   if (segT > 0) { rb = rk / segT; rt = rk - rb * segT; }
   const long shiftB = g.shift ? 1 : 0;
   const float *pa, *pb;
-  float bsc = 1.0f;                   // per-sequence factor on B's rows (wave-uniform; reloaded when the sequence changes)
   const int nseq_k = segT > 0 ? (g.K + segT - 1) / segT : 1;
   auto rowptrs = [&]() {
     const long rowA = segT > 0 ? (long)rb * g.a_seg + rt : (long)rk;
     const long rowB = (segT > 0 ? (long)rb * g.b_seg + rt : (long)rk) - shiftB;
     pa = g.A + rowA * g.sak;
     pb = g.B + rowB * g.sbk;          // with shift at rt == 0 this is never dereferenced
-    if (g.bscale && segT > 0) bsc = g.bscale[min(rb, nseq_k - 1)];
   };
   rowptrs();
   auto advance = [&](int d) {
@@ -171,7 +170,7 @@ __device__ __forceinline__ void wgrad_tile_bf16(const GemmArgs& g, const int bx,
     const bool inB = in && !(g.shift && rt == 0);
     ra[j] = gload4((in ? pa : g.A) + a_lane);
     rbv[j] = gload((inB ? pb : g.B) + b_lane);
-    rsc[j] = bsc;
+    if (SCALED) rsc[j] = gload(g.bscale + min(rb, nseq_k - 1));
     if (j == 0) { okA = 0; okB = 0; }
     okA |= in ? (1u << j) : 0u;
     okB |= inB ? (1u << j) : 0u;
@@ -186,7 +185,7 @@ __device__ __forceinline__ void wgrad_tile_bf16(const GemmArgs& g, const int bx,
       const bool la = a_in && ((okA >> j) & 1u), lb = b_in && ((okB >> j) & 1u);
       va[0][j] = la ? ra[j].x : 0.0f; va[1][j] = la ? ra[j].y : 0.0f;
       va[2][j] = la ? ra[j].z : 0.0f; va[3][j] = la ? ra[j].w : 0.0f;
-      vb[j] = lb ? rbv[j] * rsc[j] : 0.0f;
+      vb[j] = lb ? (SCALED ? rbv[j] * rsc[j] : rbv[j]) : 0.0f;
     }
     if (lane < GB_MT * 4) {
 #pragma unroll
@@ -262,14 +261,16 @@ extern "C" __global__ __launch_bounds__(256) void s2g_k_gemm_grouped_bf16(const 
     const int bz = lid / tiles, t = lid - bz * tiles;
     while (p + 1 < nprob && t >= prefix[p + 1]) ++p;
     const GemmArgs gs = table[p];
-    wgrad_tile_bf16(gs, t - prefix[p], bz, At, Bt);
+    if (gs.bscale != nullptr && gs.segT > 0) wgrad_tile_bf16<true>(gs, t - prefix[p], bz, At, Bt);
+    else wgrad_tile_bf16<false>(gs, t - prefix[p], bz, At, Bt);
     return;
   }
   while (p + 1 < nprob && lid >= prefix[p + 1]) ++p;
   const GemmArgs gs = table[p];
   const int local = lid - prefix[p];
   const int nx = (gs.N + 63) / 64;
-  wgrad_tile_bf16(gs, local % nx, local / nx, At, Bt);
+  if (gs.bscale != nullptr && gs.segT > 0) wgrad_tile_bf16<true>(gs, local % nx, local / nx, At, Bt);
+  else wgrad_tile_bf16<false>(gs, local % nx, local / nx, At, Bt);
 }
 
 extern "C" int s2g_launch_gemm_grouped_bf16(const GemmArgs* table_dev, const int* prefix_dev, int nprob,

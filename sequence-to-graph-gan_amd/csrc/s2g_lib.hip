@@ -154,6 +154,11 @@ int s2g_gemm_grouped(const GemmArgs* table_dev, const int* prefix_dev, int nprob
   if (nz > 0 && total_blocks % nz) return -1;
   return s2g_launch_gemm_grouped(table_dev, prefix_dev, nprob, total_blocks, nz, ST(stream));
 }
+int s2g_reduce_slabs_weighted(const float* slabs, long slab, int nslab, const float* weights, float* out, long n,
+                              void* stream) {
+  if (!slabs || !weights || !out || nslab <= 0 || n <= 0 || slab < n) return -1;
+  return s2g_launch_reduce_slabs_weighted(slabs, slab, nslab, weights, out, n, ST(stream));
+}
 int s2g_gemm_grouped_bf16(const GemmArgs* table_dev, const int* prefix_dev, int nprob, int total_blocks, int nz,
                           void* stream) {
   if (!table_dev || !prefix_dev || nprob <= 0 || nprob > 64 || total_blocks <= 0 || nz < 0) return -1;

@@ -103,7 +103,7 @@ class CriticEngine:
         built, self._pending_built = self._pending_built, None
         if built is None:
             raise S2GError("fused_update: no critic_iteration(defer_reduce=True) pending")
-        _, job_slabs, slabs = built
+        _, job_slabs, slabs = built[:3]
         names = ("lstm.weight_ih_l0", "lstm.weight_hh_l0", "lstm.weight_ih_l1", "lstm.weight_hh_l1")
         off = self.params.offsets
         u = S2GCriticUpdate()
@@ -401,19 +401,26 @@ def _wgrad(eng: "CriticEngine", out: torch.Tensor, N: int, terms) -> None:
 
 
 def _wgrad_build(eng: "CriticEngine", jobs, cache_key):
-    """jobs: list of (out tensor [200,N] torch layout, N, terms); a term is
-    (A_ptr, K, B_ptr, sbk, sbn, segT, a_seg, b_seg, shift[, phase]).  All products of one phase run
-    in ONE grouped GEMM launch; every product owns its split-K slabs.  The slabs of a job are laid out [phases before the last | one slot
-    for their sum | last phase], so the early reduce (phases before the last -> the slot) runs while the
-    last phase is still being computed and the final reduce reads the slot and the last phase only.
-    Returns (tables {phase: (table, prefix, nprob, nblocks)}, job_slabs, slabs); the device-side tables
-    are cached per `cache_key` and rebuilt only when a pointer or size changes."""
+    """jobs: list of (out tensor [200,N] torch layout, N, terms[, options]); a term is
+    (A_ptr, K, B_ptr, sbk, sbn, segT, a_seg, b_seg, shift[, phase[, bscale_ptr]]) -- bscale: one factor per sequence
+    (segT > 0) on the rows of B.  All products of one phase run in ONE grouped GEMM launch; every product owns its
+    split-K slabs.  The slabs of a job are laid out [phases before the last | extra | one slot for their sum | last
+    phase], so the early reduce (everything in front of the slot -> the slot) runs while the last phase is still
+    being computed and the final reduce reads the slot and the last phase only.
+    options: {"extra": n} reserves n more slabs in front of the slot that the CALLER fills (contributions that are
+    not products of this launch, in the job's internal row order) before the early reduce;
+    {"manual": True}: the job takes no part in the reduces here (the caller sums its slabs itself);
+    {"kchunk": rows}: rows per split-K slab of this job's products (a multiple of 32) instead of the phase's.
+    Returns (tables {phase: (table, prefix, nprob, nblocks)}, job_slabs, slabs, info) with
+    info[job index] = dict(extra=[element offsets of the extra slabs], base, nslabs, slab);
+    the device-side tables are cached per `cache_key` and rebuilt only when a pointer or size changes."""
     from .lib import S2GGemm
-    last = max((term[9] if len(term) > 9 else 0) for _, _, terms in jobs for term in terms)
+    jobs = [j if len(j) > 3 else (*j, {}) for j in jobs]
+    last = max((term[9] if len(term) > 9 else 0) for _, _, terms, o in jobs for term in terms if not o.get("manual"))
     # K-chunk per phase: 1024 rows unless that leaves the launch with fewer than ~3 blocks per CU
     # (the kernel hides its loads behind the MFMAs of the other blocks on the CU)
     chunk = {}
-    for _, N, terms in jobs:
+    for _, N, terms, _o in jobs:
         for term in terms:
             ph = term[9] if len(term) > 9 else 0
             chunk.setdefault(ph, []).append(((N + 63) // 64, term[1]))
@@ -422,35 +429,49 @@ def _wgrad_build(eng: "CriticEngine", jobs, cache_key):
         while c > 256 and sum(t * ((K + c - 1) // c) for t, K in lst if K > 0) < 700:
             c //= 2
         chunk[ph] = c
-    plan, sig, job_slabs = [], [], []
+    plan, sig, job_slabs, info = [], [], [], {}
     base = 0
-    for out, N, terms in jobs:
+    for ji, (out, N, terms, opts) in enumerate(jobs):
         slab = G4 * N
         tiles = (N + 63) // 64                               # (all 200 rows) x 64 output tiles
+        manual, n_extra = bool(opts.get("manual")), int(opts.get("extra", 0))
         early, late = [], []
         for term in terms:
             A, K, B, sbk, sbn, segT, a_seg, b_seg, shift = term[:9]
             phase = term[9] if len(term) > 9 else 0
+            bscale = term[10] if len(term) > 10 else None
             if K <= 0:
                 continue
-            c = chunk[phase]
-            ns = max(1, min(256, (K + c // 2) // c))
-            kchunk = ((K + ns - 1) // ns + 31) // 32 * 32
+            if opts.get("kchunk"):                         # the caller fixes the rows per slab (a multiple of 32)
+                kchunk = int(opts["kchunk"])
+            else:
+                c = chunk[phase]
+                ns = max(1, min(256, (K + c // 2) // c))
+                kchunk = ((K + ns - 1) // ns + 31) // 32 * 32
             ns = (K + kchunk - 1) // kchunk
-            (late if phase == last else early).append((phase, A, K, B, sbk, sbn, segT, a_seg, b_seg, shift, N, kchunk, ns))
+            (late if (phase == last and not manual) else early).append(
+                (phase, A, K, B, sbk, sbn, segT, a_seg, b_seg, shift, N, bscale, kchunk, ns))
         n_early = sum(e[-1] for e in early)
         n_late = sum(e[-1] for e in late)
         pos = 0
         for e in early:
             plan.append(e[:-1] + (base + pos * slab, slab, tiles * e[-1]))
-            sig.append(e[:11])
+            sig.append(e[:12])
             pos += e[-1]
-        pos = n_early + (1 if n_early else 0)             # the slot for the early sum
+        extra = [base + (pos + k) * slab for k in range(n_extra)]
+        pos += n_extra
+        if manual:
+            info[ji] = dict(extra=extra, base=base, nslabs=pos, slab=slab)
+            base += pos * slab
+            continue
+        n_front = pos                                      # slabs the early reduce sums into the slot
+        pos = n_front + (1 if n_front else 0)              # the slot for the early sum
         for e in late:
             plan.append(e[:-1] + (base + pos * slab, slab, tiles * e[-1]))
-            sig.append(e[:11])
+            sig.append(e[:12])
             pos += e[-1]
-        job_slabs.append((out, n_early, n_late, slab, base))
+        job_slabs.append((out, n_front, n_late, slab, base))
+        info[ji] = dict(extra=extra, base=base, nslabs=pos, slab=slab)
         base += pos * slab
     if eng._wgrad_slabs is None or eng._wgrad_slabs.numel() < base:
         eng._wgrad_slabs = torch.empty(max(base, 1), dtype=torch.float32, device=eng.device)
@@ -465,11 +486,11 @@ def _wgrad_build(eng: "CriticEngine", jobs, cache_key):
             prefix, blocks = [], 0
             # every product of the phase cut into the same number of K-chunks: blocks ordered K-chunk
             # first (prefix counts output tiles), so products sharing an operand meet its rows in L2
-            nzs = {(e[2] + e[11] - 1) // e[11] for e in sel}
+            nzs = {(e[2] + e[12] - 1) // e[12] for e in sel}
             nz = nzs.pop() if len(nzs) == 1 else 0
-            for i, (_, A, K, B, sbk, sbn, segT, a_seg, b_seg, shift, N, kchunk, soff, slab, nblk) in enumerate(sel):
+            for i, (_, A, K, B, sbk, sbn, segT, a_seg, b_seg, shift, N, bscale, kchunk, soff, slab, nblk) in enumerate(sel):
                 arr[i] = S2GGemm(A, 1, G4, B, sbk, sbn, ptr(slabs, soff), N, slab, None, G4, N, K, kchunk, segT,
-                                 a_seg, b_seg, int(shift), 0, 0, 1.0)
+                                 a_seg, b_seg, int(shift), 0, 0, 1.0, bscale)
                 prefix.append(blocks)
                 blocks += (N + 63) // 64 if nz else nblk
             prefix.append(blocks)
@@ -480,7 +501,7 @@ def _wgrad_build(eng: "CriticEngine", jobs, cache_key):
             tables[ph] = (raw, pre, len(sel), blocks, nz)
         cache = (sig, tables)
         eng._gemm_tables[cache_key] = cache
-    return cache[1], job_slabs, slabs
+    return cache[1], job_slabs, slabs, info
 
 
 def _wgrad_launch(eng: "CriticEngine", built, phase: int) -> None:
@@ -496,7 +517,7 @@ def _wgrad_reduce(eng: "CriticEngine", built, early: bool = False) -> None:
     """early: sums every job's slabs of the phases before the last into the job's slot (internal row
     order, may run beside the last phase); otherwise: slot + last phase -> the torch-layout gradient."""
     from .lib import S2GReduce
-    _, job_slabs, slabs = built
+    _, job_slabs, slabs = built[:3]
     live = []
     for out, n_early, n_late, slab, base in job_slabs:
         if early:
@@ -570,9 +591,13 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         raise S2GError("critic_iteration: desc must be an int32 device tensor of 4*B descriptors")
     dptr = ptr(desc)
     if "Pf" not in ws or ws["Pf"].shape[0] != B * Tf:
+        from .lib import get
         ws["Pf"] = torch.empty(B * Tf, G4, device=eng.device)
-        ws["xreal"] = torch.empty(B * T, V, device=eng.device)
         ws["xhat"] = torch.empty(B * T, V, device=eng.device)
+        ws["coef"] = torch.empty(B, device=eng.device)
+        ws["gram"] = torch.empty(G4, G4, device=eng.device)
+        ws["bucket_part"] = torch.empty(int(get().s2g_embed_grad_tokens_scratch(B * T, V)) * ((G4 + 31) // 32),
+                                        device=eng.device)
     # sweep A on 3B sequences
     eng.project(fake, ws["Pf"])
     eng.kick_m2()          # a rebuild of M2 left over from the last update: beside sweep A, whose 192 workgroups leave CUs free
@@ -609,13 +634,22 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
     a0, a1, cd0, cd1 = ws["abar0"], ws["abar1"], ws["celld0"], ws["celld1"]
     oi = r_int * G4
     n12, n3 = 2 * B * Tw, B * Tw
-    # weight-gradient products; the last field is the phase = the last sweep the product needs:
-    # 0 = A/B, 1 = C (tangent states), 2 = D (adjoints abar)
+    # Weight-gradient products; the 10th field is the phase = the last sweep the product needs:
+    # 0 = A/B, 1 = C (tangent states), 2 = D (adjoints abar).  dW_ih0 (wgan_gp.py:277, 239, 317) in five parts:
+    #   real third   x is one-hot: sum over rows of delta0[row]^T e_token = delta0 rows bucketed by token
+    #                (s2g_bucket_rows_by_token_t, an extra slab: no one-hot operand, no product with zeros);
+    #   fake third   delta0^T fake;
+    #   penalty, first-order factor: sum_rows delta0_int[row]^T v[row] with v = coef_b (delta0_int W_ih0), i.e.
+    #                (sum_b coef_b sum_t delta0_int[b,t]^T delta0_int[b,t]) W_ih0: a 200-wide Gram product and one
+    #                200 x 200 x V product (an extra slab) -- the 175-wide direction v is never formed.  With one
+    #                split-K slab per sequence the Gram product needs no coefficient (phase 0) and the slab sum
+    #                applies coef_b; when a sequence's rows are no multiple of 32 the factor rides on one operand
+    #                instead (phase 1, when coef is known);
+    #   penalty, second-order factor: abar0^T x_hat (phase 2).
+    coef = ws["coef"]
     jobs = [(g["lstm.weight_ih_l0"], V, [
-        (ptr(d0), B * T, ptr(ws["xreal"]), V, 1, T, Tw, T, False, 0),
         (ptr(d0, B * Tw * G4), B * Tf, ptr(fake), V, 1, Tf, Tw, Tf, False, 0),
-        (ptr(d0, oi), n3, ptr(ws["G"]), V, 1, 0, 0, 0, False, 0),
-        (ptr(a0), B * T, ptr(ws["xhat"]), V, 1, T, Tw, T, False, 2)]),
+        (ptr(a0), B * T, ptr(ws["xhat"]), V, 1, T, Tw, T, False, 2)], {"extra": 2}),
             (g["lstm.weight_hh_l0"], H, [
         (ptr(d0), n3, ptr(c0, 2), G4, 4, Tw, Tw, Tw, True, 0),
         (ptr(d0, oi // 2), n3, ptr(c0, oi // 2 + 2), G4, 4, Tw, Tw, Tw, True, 0),
@@ -630,24 +664,41 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         (ptr(d1), n3, ptr(c1, 2), G4, 4, Tw, Tw, Tw, True, 0),
         (ptr(d1, oi // 2), n3, ptr(c1, oi // 2 + 2), G4, 4, Tw, Tw, Tw, True, 0),
         (ptr(a1), n3, ptr(c1, oi + 2), G4, 4, Tw, Tw, Tw, True, 2),
-        (ptr(d1, oi), n3, ptr(cd1, 1), G4, 4, Tw, Tw, Tw, True, 1)])]
+        (ptr(d1, oi), n3, ptr(cd1, 1), G4, 4, Tw, Tw, Tw, True, 1)]),
+            (ws["gram"], G4, [
+        (ptr(d0, oi), n3, ptr(d0, oi), G4, 1, Tw, Tw, Tw, False, 0)], {"manual": True, "kchunk": Tw}) if Tw % 32 == 0 else
+            (ws["gram"], G4, [
+        (ptr(d0, oi), n3, ptr(d0, oi), G4, 1, Tw, Tw, Tw, False, 1, ptr(coef))], {"manual": True})]
     built = _wgrad_build(eng, jobs, ("critic", B, T, Tf, fake.data_ptr()))
+    slabs, info = built[2], built[3]
+    slab_real, slab_gram = info[0]["extra"]
     side = eng.side() if eng.overlap else None
 
     def first_order(sc):
-        """Everything that needs sweeps A and B only: operands of the products, their phase-0 part, the
-        first-order bias gradients."""
+        """Everything that needs sweeps A and B only: operands of the products and their phase-0 part."""
         s_ = stream_ptr()
-        # g = delta0 W_ih0, the 175-wide input gradient itself: penalty values and norms (wgan_gp.py:255-256)
-        # and, scaled in place, v = coef_b * g: the direction of the penalty's second-order term in input
-        # space.  Nothing here waits for the reduction the caller's stream does for sweep C.
-        ops.gemm_tall(ptr(ws["delta0"], r_int * G4), G4, ptr(eng.W0p), eng.Vp, ptr(ws["G"]), V, B * Tw, V, G4,
-                      bf16=eng.bf16)
-        call("s2g_gp_norm_penalty", ptr(ws["G"]), B, Tw * V, float(lambda_gp), float(n_global), ptr(ws["pen"]),
-             ptr(ws["norms"]), 1, s_)
-        call("s2g_one_hot", ptr(tokens), ptr(lengths), T, ptr(ws["xreal"]), B * T, V, s_)
         call("s2g_gp_interp", ptr(tokens), ptr(lengths), ptr(fake), ptr(alpha), B, T, Tf, V, ptr(ws["xhat"]), s_)
         _wgrad_launch(eng, built, 0)
+
+    def real_third():
+        """dW_ih0 of the real third, [gate row][token], straight into its slab"""
+        call("s2g_bucket_rows_by_token_t", ptr(tokens), ptr(lengths), T, B * T, V, ptr(d0), G4, Tw, G4,
+             ptr(slabs, slab_real), V, ptr(ws["bucket_part"]), stream_ptr())
+
+    def after_tangent():
+        """What needs the penalty's reduction (ordered behind it by the caller): penalty values, norms and the
+        per-sample coefficient (wgan_gp.py:255-256), the phase-1 products with the Gram product among them, its
+        slab sum, and its product with W_ih0 into dW_ih0's second extra slab."""
+        call("s2g_gp_penalty_final", ptr(ws["gp_partial"]), B, float(lambda_gp), float(n_global), ptr(ws["pen"]),
+             ptr(ws["norms"]), ptr(coef), stream_ptr())
+        _wgrad_launch(eng, built, 1)
+        gi = info[4]
+        if Tw % 32 == 0:        # one slab per sequence: the slab sum applies the per-sample coefficient
+            call("s2g_reduce_slabs_weighted", ptr(slabs, gi["base"]), gi["slab"], gi["nslabs"], ptr(coef), ptr(ws["gram"]),
+                 G4 * G4, stream_ptr())
+        else:
+            ops.reduce_slabs(slabs[gi["base"]:], gi["slab"], gi["nslabs"], G4, G4, ws["gram"])
+        ops.gemm_raw(ptr(ws["gram"]), G4, 1, ptr(eng.W0p), eng.Vp, 1, ptr(slabs, slab_gram), V, G4, V, G4)
 
     def bias_sums(sums, nseq, hdot, accumulate):
         """bias gradients of both layers from the per-sequence sums the reverse sweeps leave behind
@@ -701,12 +752,15 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         join_g, after_d = eng._iter_events
         with ops.on_stream(small):
             small.wait_event(fork)
+            real_third()
             head_losses()
             first_order_sums(sc2)
             join_g.record()
         with ops.on_stream(stream2):
-            stream2.wait_event(after_c)
-            _wgrad_launch(eng, built, 1)
+            stream2.wait_event(after_c)         # (sweep C is queued behind the penalty's reduction)
+            after_tangent()
+            if small is not stream2:
+                stream2.wait_event(join_g)      # the bucketed real third is one of the slabs summed next
             _wgrad_reduce(eng, built, early=True)
             join.record()
             if prefetch is not None and eng.stream_g is None:
@@ -748,8 +802,9 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         eng.timed("s2g_k_lstm2_bwd2", lambda: eng.sweep_bwd2(ws, drel, B, Tw, mrel, r_int, bsum=ws["bsumD"]))
         head_losses()
         first_order(sc)
+        real_third()
         first_order_sums(sc)
-        _wgrad_launch(eng, built, 1)
+        after_tangent()
         _wgrad_reduce(eng, built, early=True)
         if prefetch is not None:
             prefetch()

@@ -73,6 +73,7 @@ SIGNATURES = {
     "s2g_gemm_tall_bf16": [P, L, P, L, P, L, I, I, I, P],
     "s2g_gemm_grouped": [P, P, I, I, I, P],
     "s2g_gemm_grouped_bf16": [P, P, I, I, I, P],
+    "s2g_reduce_slabs_weighted": [P, L, I, P, P, L, P],
     "s2g_generate_tokens": [P, P, P, P, P, I, I, I, I, U64, U64, P],
     "s2g_linear_small_batch": [P, P, P, P, I, I, I, I, P],
     "s2g_linear_wgrad_adam": [P, P, P, P, P, P, I, I, I, F, F, F, F, I, I, P],

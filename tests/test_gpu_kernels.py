@@ -526,3 +526,55 @@ def test_small_linear_grads_match_torch(M):
             assert rel(db.cpu(), rb) < 1e-5
     with pytest.raises(lib.S2GError):
         ops.small_linear_grads([(jobs[0][0], jobs[1][1], jobs[0][2], None)])      # dW shape does not match x
+
+
+@pytest.mark.parametrize("B,T,Tw,V,W", [(5, 37, 41, 175, 200), (64, 512, 512, 175, 200), (3, 16, 16, 23, 40)])
+def test_bucketed_row_sums_transposed_match_index_add(B, T, Tw, V, W):
+    """s2g_bucket_rows_by_token_t: out[c][v] = sum over live rows with token v of x[row][c] for a width that is no
+    multiple of 32, rows laid out Tw >= T per sequence, ragged lengths -- the real third of dW_ih0 -- against
+    index_add in float64."""
+    from s2g.lib import call, get
+    from s2g.ops import ptr, stream_ptr
+    g = common.gen(77 + B)
+    tokens = torch.randint(0, V, (B, T), generator=g, dtype=torch.int32)
+    lengths = torch.randint(1, T + 1, (B,), generator=g, dtype=torch.int32)
+    lengths[0] = T
+    x = torch.randn(B * Tw + 3, W, generator=g)              # a few rows beyond the last sequence: never read as live
+    want = torch.zeros(V, W, dtype=torch.float64)
+    for b in range(B):
+        n = int(lengths[b])
+        want.index_add_(0, tokens[b, :n].long(), x[b * Tw:b * Tw + n].double())
+    out = torch.full((W, V), float("nan"), device=DEV)
+    part = torch.empty(int(get().s2g_embed_grad_tokens_scratch(B * T, V)) * ((W + 31) // 32), device=DEV)
+    tok_d, len_d, x_d = tokens.to(DEV), lengths.to(DEV), x.to(DEV)
+    call("s2g_bucket_rows_by_token_t", ptr(tok_d), ptr(len_d), T, B * T, V, ptr(x_d), W, Tw, W, ptr(out), V, ptr(part),
+         stream_ptr())
+    torch.cuda.synchronize()
+    assert rel(out.double().cpu(), want.T) < 1e-5
+
+
+@pytest.mark.parametrize("fn", ["s2g_gemm_grouped", "s2g_gemm_grouped_bf16"])
+def test_gemm_grouped_row_scale(fn):
+    """S2GGemm.bscale: one factor per sequence on the rows of B -- the weighted Gram product
+    sum_rows coef[seq(row)] A[row]^T A[row] of the penalty's first-order factor."""
+    from s2g.lib import S2GGemm, call
+    from s2g.ops import ptr, stream_ptr
+    g = common.gen(91)
+    nb, T = 7, 53
+    rnd = (lambda t: t.bfloat16().float()) if fn.endswith("bf16") else (lambda t: t)
+    A = rnd(torch.randn(nb * T, 200, generator=g)).to(DEV)
+    # factors that are exact in bf16 too (the kernel multiplies the fp32 row before rounding it)
+    coef = torch.tensor([0.5, -2.0, 1.0, 4.0, 0.25, -1.0, 8.0]).to(DEV)
+    want = (A.double() * coef.double().repeat_interleave(T).unsqueeze(1)).T @ A.double()
+    kchunk = 64
+    K = nb * T
+    nz = (K + kchunk - 1) // kchunk
+    out = torch.full((nz, 200, 200), float("nan"), device=DEV)
+    arr = (S2GGemm * 1)()
+    arr[0] = S2GGemm(ptr(A), 1, 200, ptr(A), 200, 1, ptr(out), 200, 200 * 200, None, 200, 200, K, kchunk, T, T, T, 0, 0, 0,
+                     1.0, ptr(coef))
+    raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(DEV)
+    pre = torch.tensor([0, 4], dtype=torch.int32, device=DEV)
+    call(fn, ptr(raw), ptr(pre), 1, 4 * nz, nz, stream_ptr())
+    torch.cuda.synchronize()
+    assert rel(out.double().sum(0), want.T) < 1e-5
