@@ -187,3 +187,36 @@ def test_train_wgan_matches_reference_train_wgan(golden, Tf, tmp_path):
     torch.save(gen.state_dict(), path)
     g2 = M.Generator(vocab_size=175, seq_len=Tf)
     g2.load_state_dict(torch.load(path, weights_only=True))
+
+
+def test_user_level_double_backward_through_discriminator(golden):
+    """The reference's own penalty code (wgan_gp.py:228-256) written against OUR Discriminator: interpolate, pack,
+    D(packed)[:, 0], autograd.grad(..., create_graph=True, retain_graph=True), per-sample norm, mean; then the backward
+    of 10 * gp.  Discriminator.forward's backward is differentiable (tangent + second reverse sweep), so the
+    second-order parameter gradients must match what the reference's autograd produced (g4), as the fused
+    compute_gradient_penalty does."""
+    import wgan_gp as M
+    G = golden("g4_gp.pt")
+    tokens, labels, lengths = common.batch(402, 5, 12, lengths=[12, 12, 9, 4, 1])
+    real = F.one_hot(tokens, 175).float().to(DEV)
+    for scale, tag in ((1.0, "s1"), (3.0, "s3")):
+        for Tf in (7, 12, 15):
+            k = f"{tag}.Tf{Tf}"
+            D = M.Discriminator(175, 50, 2, 2, drop_rate=0.0)
+            D.load_state_dict(common.critic_params(401, scale=scale))
+            D = D.to(DEV).train()
+            fake, alpha = G[f"{k}.fake"].to(DEV), G[f"{k}.alpha"].to(DEV)
+            padded_fake = F.pad(fake, (0, 0, 0, real.size(1) - fake.size(1)))                      # :231-233
+            interpolates = (alpha * real + (1 - alpha) * padded_fake).requires_grad_(True)           # :239
+            packed = pack_padded_sequence(interpolates, lengths, batch_first=True, enforce_sorted=False)
+            d_interpolates = D(packed)[:, 0]                                                         # :244
+            gradients = torch.autograd.grad(outputs=d_interpolates, inputs=interpolates,
+                                            grad_outputs=torch.ones(d_interpolates.size(), device=DEV),
+                                            create_graph=True, retain_graph=True)[0]                 # :247-254
+            gradients = gradients.view(gradients.size(0), -1)
+            gp = ((gradients.norm(2, dim=1) - 1) ** 2).mean()                                        # :255-256
+            assert_close(gp.detach().cpu(), G[f"{k}.gp"], TOL, "gp")
+            (10.0 * gp).backward()
+            for n, p in D.named_parameters():
+                if f"{k}.grad.{n}" in G:
+                    assert_close(p.grad.cpu(), G[f"{k}.grad.{n}"], TOL, f"{k} {n}", atol=1e-7)
