@@ -191,7 +191,7 @@ extern "C" __global__ __launch_bounds__(256) void s2g_k_small_dw(S2GSmallDw a) {
   const int ldy = a.n_out[j], ldx = a.n_in[j];
   f4 acc = {0.f, 0.f, 0.f, 0.f};
   float sb = 0.0f;
-#pragma unroll 8
+#pragma unroll 32
   for (int b = 0; b < a.batch; ++b) {
     const float d = dy[(size_t)b * ldy];
     const f4 xv = *reinterpret_cast<const f4*>(x + (size_t)b * ldx);

@@ -84,9 +84,11 @@ def gemm_tall(A: int, lda: int, B: int, ldb: int, C: int, ldc: int, M: int, N: i
         gemm_raw(A, lda, 1, B, ldb, 1, C, ldc, M, N, K)
 
 
-def pick_split(M: int, N: int, K: int, target_blocks: int = 768) -> int:
+def pick_split(M: int, N: int, K: int, target_blocks: int = 768, min_chunk: int = 128) -> int:
+    """Split-K factor of a product with M x N outputs over K: enough blocks to fill the chip, at least
+    `min_chunk` reduction rows per block."""
     tiles = ((M + 63) // 64) * ((N + 63) // 64)
-    ns = max(1, min(target_blocks // max(tiles, 1), (K + 127) // 128))
+    ns = max(1, min(target_blocks // max(tiles, 1), (K + min_chunk - 1) // min_chunk))
     return ns
 
 
@@ -167,7 +169,10 @@ def linear_bwd_dx(dy: torch.Tensor, W: torch.Tensor, dx: torch.Tensor, scratch: 
     M, N = dy.shape
     K = W.shape[1]
     _chk(dy, name="dy"); _chk(W, name="W"); _chk(dx, name="dx")
-    ns = pick_split(M, K, N)
+    # a one-tile-row product (the generator's batch of 64) is a chain of dependent load rounds, one per 32
+    # reduction rows of a block; beside an HBM-saturating kernel a round costs several microseconds, so such a
+    # product is cut down to ONE round per block (32 rows) and one more for the slab sum
+    ns = pick_split(M, K, N, min_chunk=32 if M <= 64 else 128)
     if ns == 1:
         gemm_raw(ptr(dy), N, 1, ptr(W), K, 1, ptr(dx), K, M, K, N)
     else:
