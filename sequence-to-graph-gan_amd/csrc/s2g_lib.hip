@@ -659,6 +659,9 @@ int s2g_bucket_rows_by_label(const long long* labels, int B, int n_classes, cons
   hipLaunchKernelGGL(s2g_k_bucket_rows_by_label, dim3(n_classes), dim3(width), 0, ST(stream), labels, B, x, width, out);
   return LAUNCH_OK();
 }
+#ifndef S2G_BUCKET_BLOCKS
+#define S2G_BUCKET_BLOCKS 256
+#endif
 static int bucket_rows_by_token(const int* tokens, const int* lengths, int T, long rows, int V, const float* dx, int ld,
                                 int width, float* demb, int ldo, int accumulate, float* part, void* stream, int x_seg,
                                 int transposed) {
@@ -673,7 +676,7 @@ static int bucket_rows_by_token(const int* tokens, const int* lengths, int T, lo
   const int nsl = (width + 31) / 32;
   // rows per workgroup: about one workgroup per CU over all column slices (a workgroup zeroes and flushes whole
   // tables, so short chunks of wide matrices are all overhead); never below EG_CHUNK, the unit the scratch is sized by
-  long chunk = ((rows * nsl / 256 + EG_CHUNK - 1) / EG_CHUNK) * EG_CHUNK;
+  long chunk = ((rows * nsl / S2G_BUCKET_BLOCKS + EG_CHUNK - 1) / EG_CHUNK) * EG_CHUNK;
   chunk = chunk < EG_CHUNK ? EG_CHUNK : (chunk > 16 * EG_CHUNK ? 16 * EG_CHUNK : chunk);
   const int nchunks = (int)((rows + chunk - 1) / chunk);
   hipLaunchKernelGGL(s2g_k_embed_grad_tokens_part, dim3(nchunks, nsl), dim3(32 * EG_GROUPS), lds, ST(stream), tokens,
