@@ -211,7 +211,15 @@ class GeneratorEngine:
 
     def small_layers_replicated(self) -> bool:
         """True when the small layers run on the global batch on every rank (several ranks): their gradients
-        come out global and identical everywhere, so only the output Linear's bucket is all-reduced."""
+        come out global and identical everywhere and are not summed over the ranks."""
+        return bool(self.comm.split)
+
+    def output_layer_factors_gathered(self) -> bool:
+        """True when backward() forms the output Linear's gradients from the GLOBAL batch's factors (several
+        ranks): dW = dl2^T a3 has rank <= batch, so the ranks exchange their rows of dl2 [B, L*V] (one all-gather,
+        world * B * L*V floats received) instead of summing the 512 x L*V products (an all-reduce of the whole
+        matrix: 2 (world - 1) / world of 184 MB per rank at L*V = 89 600); a3 of the global batch is on every rank
+        already.  The gradient comes out global and bit-identical everywhere."""
         return bool(self.comm.split)
 
     def last_layer_range(self):
@@ -222,15 +230,18 @@ class GeneratorEngine:
 
     def backward(self, dy: torch.Tensor, last_layer=None) -> None:
         """Fills self.grads from d loss/d y (this rank's samples, losses normalised by the GLOBAL batch).
-        One process: the gradient.  Several ranks: the output Linear's entries are this rank's share (summing
-        them over the ranks gives the global gradient); d(a3) of all ranks is gathered and the small layers'
-        backward runs on the global batch, so THEIR entries are the global gradient already, identical on
-        every rank, and must not be summed again (small_layers_replicated()).
+        One process: the gradient.  Several ranks: d(a3) of all ranks is gathered and the small layers' backward
+        runs on the global batch; the output Linear's gradients are formed from the gathered rows of dl2 and the
+        global a3 (output_layer_factors_gathered()).  Every entry is then the global gradient, identical on every
+        rank, and must not be summed over the ranks again.
 
-        last_layer: optional callable(dl2, a3) that takes over the output Linear's gradients (the
+        last_layer: optional callable(dl2, a3, gather) that takes over the output Linear's gradients (the
         trainer runs them, and that layer's update, on a second stream beside the rest of this
         backward: a chain of small launch-bound kernels); it must keep dl2 alive until its work is
-        ordered before the caller's stream again."""
+        ordered before the caller's stream again.  gather (several ranks, else None): the all-gather the callee
+        applies to dl2 on ITS stream before it forms the gradients -- a3 is the global batch's then.  The gather
+        of d(a3), which the rest of this backward waits for, is issued first: collectives of one communicator run
+        in issue order, and the small message must not queue behind the large one."""
         s = self.saved
         if not s:
             raise S2GError("generator.backward called without a saved forward")
@@ -240,12 +251,14 @@ class GeneratorEngine:
         dl2 = dlogits.view(Bl, self.L * self.V)
         da3 = torch.empty(Bl, 512, device=dev)
         ops.linear_bwd_dx(dl2, p["model.8.weight"], da3, sc)
-        if last_layer is None:
-            self.last_layer_grads(dl2, s["a3"], sc)
-        else:
-            last_layer(dl2, s["a3"])
         if B != Bl:
             da3 = self.comm.allgather_rows(da3)     # [B_global, 512], rank order = row order of the global batch
+        gather = self.comm.allgather_rows if self.output_layer_factors_gathered() else None
+        a3 = s["a3_all"] if gather is not None else s["a3"]
+        if last_layer is None:
+            self.last_layer_grads(gather(dl2) if gather is not None else dl2, a3, sc)
+        else:
+            last_layer(dl2, a3, gather)
         # the chain d(a3) -> d(x0) first (every link waits for the one before), then the weight and bias
         # gradients of the three small layers, which hang off it, in ONE launch
         dpre3 = self._bn_bwd(s["a3_all"], da3, s["xhat3"], s["inv3"], "model.6", B, 512)

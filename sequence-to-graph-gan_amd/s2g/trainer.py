@@ -330,19 +330,23 @@ class WGANGPTrainer:
         losses, dfake = critic_forward_backward_fake(self.D, fake, labels, n_global, 1.0 / wsum, mask, CLASS_W)
         side = self.D.side() if (update and self.D.overlap) else None
         lo, hi = self.G.last_layer_range()
-        # several ranks: the small layers' gradients are global and identical on every rank already (computed on the
-        # gathered global batch); only the output Linear's bucket is all-reduced
+        # several ranks: every generator gradient is global and identical on every rank already -- the small layers'
+        # (computed on the gathered global batch) and the output Linear's (formed from the gathered rows of dl2)
         small_reduce = not self.G.small_layers_replicated()
+        out_reduce = not self.G.output_layer_factors_gathered()
         # one process and a batch the kernel takes: the output Linear's weight gradient and its Adam step in ONE
-        # pass over W, m, v (6 passes over 184 MB instead of 10); with several ranks the gradient must be
-        # all-reduced first, so the product and the flat Adam stay separate
+        # pass over W, m, v (6 passes over 184 MB instead of 10); the kernel takes up to 64 rows, so with several
+        # ranks (the rows of the GLOBAL batch) the product and the flat Adam stay separate
         fused_out = update and not self.comm.split and ops.linear_wgrad_adam_ok(B, self.G.params.views["model.8.weight"].shape[1])
 
-        def last_layer_update(dl2, a3, workgroups=0):
-            """gradients and Adam step of the output Linear (weight and bias) on the current stream"""
+        def last_layer_update(dl2, a3, workgroups=0, gather=None):
+            """gradients and Adam step of the output Linear (weight and bias) on the current stream;
+            gather: all-gather of dl2's rows over the ranks first (a3 is the global batch's then)"""
+            if gather is not None:
+                dl2 = gather(dl2)
             if not fused_out:
                 self.G.last_layer_grads(dl2, a3, self._g_scratch)
-                self._adam(self.G, self.mG, self.vG, self.tG, lo, hi)
+                self._adam(self.G, self.mG, self.vG, self.tG, lo, hi, reduce=out_reduce)
                 return
             ow, nw, _ = self.G.params.offsets["model.8.weight"]
             lr, b1, b2, eps = self.adam_g
@@ -355,7 +359,7 @@ class WGANGPTrainer:
         if side is None:
             if update:
                 self.tG += 1
-                self.G.backward(dfake, last_layer=last_layer_update)
+                self.G.backward(dfake, last_layer=lambda dl2, a3, gather=None: last_layer_update(dl2, a3, 0, gather))
                 self._adam(self.G, self.mG, self.vG, self.tG, 0, lo, reduce=small_reduce)
                 self._adam(self.G, self.mG, self.vG, self.tG, hi, self.G.params.total, reduce=small_reduce)
             else:
@@ -370,13 +374,13 @@ class WGANGPTrainer:
             stream_s = side[0]
             done, keep = torch.cuda.Event(), []
 
-            def last_layer(dl2, a3):
+            def last_layer(dl2, a3, gather=None):
                 ready = torch.cuda.Event()
                 ready.record()
                 keep.extend((dl2, a3))        # allocated on this stream, read on the other: alive until the join
                 with ops.on_stream(stream_s):
                     stream_s.wait_event(ready)
-                    last_layer_update(dl2, a3, self.D.cu_masked)
+                    last_layer_update(dl2, a3, self.D.cu_masked, gather)
                     done.record()
 
             self.G.backward(dfake, last_layer=last_layer)
