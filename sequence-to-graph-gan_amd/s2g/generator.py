@@ -238,8 +238,8 @@ class GeneratorEngine:
         last_layer: optional callable(dl2, a3, gather) that takes over the output Linear's gradients (the
         trainer runs them, and that layer's update, on a second stream beside the rest of this
         backward: a chain of small launch-bound kernels); it must keep dl2 alive until its work is
-        ordered before the caller's stream again.  gather (several ranks, else None): the all-gather the callee
-        applies to dl2 on ITS stream before it forms the gradients -- a3 is the global batch's then.  The gather
+        ordered before the caller's stream again.  gather (bool; several ranks): the callee all-gathers the rows of
+        dl2 over the ranks on ITS stream before it forms the gradients -- a3 is the global batch's then.  The gather
         of d(a3), which the rest of this backward waits for, is issued first: collectives of one communicator run
         in issue order, and the small message must not queue behind the large one."""
         s = self.saved
@@ -253,10 +253,10 @@ class GeneratorEngine:
         ops.linear_bwd_dx(dl2, p["model.8.weight"], da3, sc)
         if B != Bl:
             da3 = self.comm.allgather_rows(da3)     # [B_global, 512], rank order = row order of the global batch
-        gather = self.comm.allgather_rows if self.output_layer_factors_gathered() else None
-        a3 = s["a3_all"] if gather is not None else s["a3"]
+        gather = self.output_layer_factors_gathered()
+        a3 = s["a3_all"] if gather else s["a3"]
         if last_layer is None:
-            self.last_layer_grads(gather(dl2) if gather is not None else dl2, a3, sc)
+            self.last_layer_grads(self.comm.allgather_rows(dl2) if gather else dl2, a3, sc)
         else:
             last_layer(dl2, a3, gather)
         # the chain d(a3) -> d(x0) first (every link waits for the one before), then the weight and bias

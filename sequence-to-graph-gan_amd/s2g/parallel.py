@@ -16,9 +16,11 @@ cross-sample couplings are handled explicitly:
     one all-gather of d(a3) [B_global, 512] replaces the BatchNorm-sum exchanges, after which the small
     layers' gradients are computed on the global batch, identical on every rank, and need no all-reduce.
 
-Gradients that do travel: the critic's as ONE flat fp32 bucket (66 k floats: latency-bound, one
-message per update), the generator's output Linear as one large message (up to 46 M floats:
-bandwidth-bound, so RCCL can use all xGMI links)."""
+What travels per update: the critic's gradients as ONE flat fp32 bucket (66 k floats: latency-bound, one
+all-reduce), and for the generator's output Linear (46 M parameters at L*V = 89 600) not the gradient but its
+factors: dW = dl2^T a3 has rank <= batch, a3 of the global batch is on every rank already, so the ranks
+all-gather their rows of dl2 [B, L*V] (world * 23 MB received at B = 64) and each forms the global gradient
+itself -- against 2 (world - 1) / world x 184 MB per rank for an all-reduce of the product."""
 from __future__ import annotations
 
 import os
@@ -50,18 +52,27 @@ class DistComm:
 
     def allgather_rows(self, t: torch.Tensor) -> torch.Tensor:
         """[rows, ...] of every rank stacked in rank order -> [world * rows, ...] (a copy for one rank)."""
+        out, wait = self.allgather_rows_start(t)
+        wait()
+        return out
+
+    def allgather_rows_start(self, t: torch.Tensor):
+        """Starts allgather_rows(t) and returns (out, wait): `out` holds the result once wait() has been called
+        (it orders the current stream behind the collective; the input is read in the order of the stream that was
+        current at the start).  Several gathers started back to back run one after the other on the communicator's
+        stream while the caller works on the results that have arrived."""
         t = t.contiguous()
         if not self.split:
-            return t.clone()
+            return t.clone(), (lambda: None)
         self.calls += 1
         out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         if dist.get_backend(self.group) == "gloo":
             if t.is_cuda:
                 torch.cuda.synchronize()
             dist.all_gather(list(out.chunk(self.world, 0)), t, group=self.group)
-        else:
-            dist.all_gather_into_tensor(out, t, group=self.group)
-        return out
+            return out, (lambda: None)
+        work = dist.all_gather_into_tensor(out, t, group=self.group, async_op=True)
+        return out, (lambda: (work.wait(), None)[1])
 
     def broadcast_int(self, value: int, device=None) -> int:
         """Rank 0's `value` on every rank (set-up time: e.g. the seed of the draws all ranks must share)."""

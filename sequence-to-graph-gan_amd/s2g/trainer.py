@@ -102,6 +102,29 @@ class WGANGPTrainer:
         lr, b1, b2, eps = self.adam_g if eng is self.G else (self.lr, self.b1, self.b2, self.eps)
         ops.adam(eng.params.flat[lo:hi], g, m[lo:hi], v[lo:hi], lr, b1, b2, eps, step)
 
+    def _out_layer_update_gathered(self, dl2: torch.Tensor, a3: torch.Tensor, update: bool, pieces: int = 4) -> None:
+        """Several ranks: gradients (and, with `update`, the Adam step) of the generator's output Linear from the
+        factors of the GLOBAL batch -- dl2 [B, L*V] of this rank, a3 [world * B, 512] of all.  The columns of dl2
+        travel in `pieces` all-gathers started back to back; the product, the bias sums and the Adam step of one
+        piece (a block of rows of W) run while the next piece is still on the links."""
+        G = self.G
+        NV, K = dl2.shape[1], a3.shape[1]
+        ow, nw, _ = G.params.offsets["model.8.weight"]
+        ob, nb, _ = G.params.offsets["model.8.bias"]
+        gW, gb = G.grads.views["model.8.weight"], G.grads.views["model.8.bias"]
+        step = (NV + pieces - 1) // pieces
+        step = (step + 3) // 4 * 4
+        cuts = [(c, min(c + step, NV)) for c in range(0, NV, step)]
+        started = [self.comm.allgather_rows_start(dl2[:, c0:c1]) for c0, c1 in cuts]
+        for (c0, c1), (rows, wait) in zip(cuts, started):
+            wait()
+            ops.linear_bwd_dw(rows, a3, gW[c0:c1], self._g_scratch)
+            ops.colsum(rows, rows.shape[0], c1 - c0, c1 - c0, gb[c0:c1], self._g_scratch)
+            if update:
+                self._adam(G, self.mG, self.vG, self.tG, ow + c0 * K, ow + c1 * K, reduce=False)
+        if update:
+            self._adam(G, self.mG, self.vG, self.tG, ob, ob + (nb + 3) // 4 * 4, reduce=False)
+
     def _gen_inputs(self, z: Optional[torch.Tensor], labels: torch.Tensor, B: int):
         """(noise, labels) as GeneratorEngine.forward takes them.  One process: this batch's z (drawn here when
         None) and labels.  Several ranks: the GLOBAL batch's -- z drawn from the key all ranks share (an
@@ -339,11 +362,12 @@ class WGANGPTrainer:
         # ranks (the rows of the GLOBAL batch) the product and the flat Adam stay separate
         fused_out = update and not self.comm.split and ops.linear_wgrad_adam_ok(B, self.G.params.views["model.8.weight"].shape[1])
 
-        def last_layer_update(dl2, a3, workgroups=0, gather=None):
+        def last_layer_update(dl2, a3, workgroups=0, gather=False):
             """gradients and Adam step of the output Linear (weight and bias) on the current stream;
-            gather: all-gather of dl2's rows over the ranks first (a3 is the global batch's then)"""
-            if gather is not None:
-                dl2 = gather(dl2)
+            gather: the rows of dl2 are all-gathered over the ranks first (a3 is the global batch's then)"""
+            if gather:
+                self._out_layer_update_gathered(dl2, a3, update)
+                return
             if not fused_out:
                 self.G.last_layer_grads(dl2, a3, self._g_scratch)
                 self._adam(self.G, self.mG, self.vG, self.tG, lo, hi, reduce=out_reduce)
@@ -359,7 +383,7 @@ class WGANGPTrainer:
         if side is None:
             if update:
                 self.tG += 1
-                self.G.backward(dfake, last_layer=lambda dl2, a3, gather=None: last_layer_update(dl2, a3, 0, gather))
+                self.G.backward(dfake, last_layer=lambda dl2, a3, gather=False: last_layer_update(dl2, a3, 0, gather))
                 self._adam(self.G, self.mG, self.vG, self.tG, 0, lo, reduce=small_reduce)
                 self._adam(self.G, self.mG, self.vG, self.tG, hi, self.G.params.total, reduce=small_reduce)
             else:
@@ -374,7 +398,7 @@ class WGANGPTrainer:
             stream_s = side[0]
             done, keep = torch.cuda.Event(), []
 
-            def last_layer(dl2, a3, gather=None):
+            def last_layer(dl2, a3, gather=False):
                 ready = torch.cuda.Event()
                 ready.record()
                 keep.extend((dl2, a3))        # allocated on this stream, read on the other: alive until the join
