@@ -353,10 +353,11 @@ def main():
         if world > 1:
             # several ranks: the same FIXED number of untimed steps on every rank (the ranks issue collectives in
             # lockstep, so none may decide by its own clock when it is warm)
-            for k in range(100):
+            n_pre = 3 if rehearse else 100      # (the gloo rehearsal stages every collective through the host)
+            for k in range(n_pre):
                 one_step(k)
             torch.cuda.synchronize()
-            prewarm = 100
+            prewarm = n_pre
         else:
             # A freshly leased box enqueues slowly for its first tens of seconds (host side: 7 ms per step against
             # 4 ms a minute later, same binary), which makes the step launch-bound.  Untimed blocks of steps run
