@@ -152,18 +152,18 @@ class CriticEngine:
         if self._m2_events is None:
             self._m2_events = (torch.cuda.Event(), torch.cuda.Event())
         packed, ready = self._m2_events
-        packed.record()
+        ops.record(packed)
         with ops.on_stream(side[1]):
             side[1].wait_event(packed)
             ops.gemm_raw(ptr(self.W0p), self.Vp, 1, ptr(self.WT0), G4, 1, ptr(self.M2), G4, G4, G4, self.V)
-            ready.record()
+            ops.record(ready)
         self._m2_pending = True
 
     def m2(self) -> torch.Tensor:
         """M2 for a reader on the current stream (ordered behind a build that runs on the side stream)."""
         self.kick_m2()
         if self._m2_pending:
-            torch.cuda.current_stream().wait_event(self._m2_events[1])
+            ops.cur_stream().wait_event(self._m2_events[1])
             self._m2_pending = False
         return self.M2
 
@@ -307,9 +307,9 @@ class CriticEngine:
             fn()
             return
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+        ops.record(e0)
         fn()
-        e1.record()
+        ops.record(e1)
         te.setdefault(name, []).append((e0, e1))
 
     def sweep_fwd(self, ws, desc_ptr, nseq, max_len, tokens, P, mask) -> None:
@@ -724,7 +724,7 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         #           second-order column sums, which run beside the last products on the caller's stream
         # stream2 : products of phase 0 beside sweep C, products of phase 1 beside sweep D
         stream2, stream_c, fork, after_c, join, join_c, sc2 = side
-        cur = torch.cuda.current_stream()
+        cur = ops.cur_stream()
         # The chain A -> B -> penalty -> C -> D -> last products is the critical path: it stays on ONE
         # stream (every hop to another stream costs ~10 us of event latency), the caller's if that is a
         # non-blocking stream.  On the NULL stream the sweeps move to stream_c instead, because the
@@ -733,11 +733,11 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
         sweeps = cur if own else stream_c
         if own:
             # fork BEFORE the penalty reduction: no event record sits between it and sweep C on this stream
-            fork.record()
+            ops.record(fork)
             gp_dots()
         else:
             gp_dots()
-            fork.record()
+            ops.record(fork)
         with ops.on_stream(stream2):
             stream2.wait_event(fork)
             first_order(sc2)
@@ -745,7 +745,7 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
             if not own:
                 stream_c.wait_event(fork)
             eng.timed("s2g_k_lstm2_tangent", lambda: eng.sweep_tangent(ws, drel, B, mrel, r_int, gp))
-            after_c.record()
+            ops.record(after_c)
         # the small launch-bound pieces (loss values + fc gradients, first-order bias sums) go beside the
         # operand / product chain of stream2, which must be through before sweep D is
         small = eng.stream_g if eng.stream_g is not None else stream2
@@ -755,14 +755,14 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
             real_third()
             head_losses()
             first_order_sums(sc2)
-            join_g.record()
+            ops.record(join_g)
         with ops.on_stream(stream2):
             stream2.wait_event(after_c)         # (sweep C is queued behind the penalty's reduction)
             after_tangent()
             if small is not stream2:
                 stream2.wait_event(join_g)      # the bucketed real third is one of the slabs summed next
             _wgrad_reduce(eng, built, early=True)
-            join.record()
+            ops.record(join)
             if prefetch is not None and eng.stream_g is None:
                 prefetch()          # not part of the join: it may run on beside this iteration's tail
         if prefetch is not None and eng.stream_g is not None:
@@ -780,7 +780,7 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
                 idle()
         with ops.on_stream(sweeps):
             eng.timed("s2g_k_lstm2_bwd2", lambda: eng.sweep_bwd2(ws, drel, B, Tw, mrel, r_int, bsum=ws["bsumD"]))
-            after_d.record()
+            ops.record(after_d)
         if idle is not None and not own:
             idle()
         if not own:
@@ -792,7 +792,7 @@ def critic_iteration(eng: CriticEngine, tokens: torch.Tensor, lengths: torch.Ten
                 stream_c.wait_event(after_d)
             stream_c.wait_event(join_g)      # the first-order bias sums and fc gradients these accumulate onto
             second_order_sums()
-            join_c.record()
+            ops.record(join_c)
         if not defer_reduce:
             _wgrad_reduce(eng, built)
         cur.wait_event(join_c)
@@ -846,15 +846,15 @@ def critic_forward_backward_fake(eng: CriticEngine, fake: torch.Tensor, labels: 
     side = eng.side() if eng.overlap else None
     if side is not None:
         fwd_done, vals_done = torch.cuda.Event(), torch.cuda.Event()
-        fwd_done.record()
+        ops.record(fwd_done)
         with ops.on_stream(side[1]):          # beside the reverse sweep
             side[1].wait_event(fwd_done)
             loss_values()
-            vals_done.record()
+            ops.record(vals_done)
     eng.sweep_bwd(ws, ptr(desc), B, Tf, mask, head=head)
     ops.gemm_tall(ptr(ws["delta0"]), G4, ptr(eng.W0p), eng.Vp, ptr(ws["dfake"]), V, B * Tf, V, G4, bf16=eng.bf16)
     if side is not None:
-        torch.cuda.current_stream().wait_event(vals_done)
+        ops.cur_stream().wait_event(vals_done)
     else:
         loss_values()
     return ws["losses"], ws["dfake"].view(B, Tf, V)

@@ -132,7 +132,7 @@ class GeneratorEngine:
             heavy_after()
         if self.last_layer_ready is not None:
             # the output Linear's update may still be running on another stream (trainer._generator_step)
-            torch.cuda.current_stream().wait_event(self.last_layer_ready)
+            ops.cur_stream().wait_event(self.last_layer_ready)
         ops.linear_fwd_small_batch(a3, p["model.8.weight"], p["model.8.bias"], logits, workgroups)
         # (U None in the Gumbel mode: the sampler draws its uniforms itself, wgan_gp.py:58)
         y, y_soft = ops.gumbel_softmax_fwd(logits.view(B, self.L, self.V), U if mode == 0 else None, tau, mode,

@@ -156,7 +156,7 @@ class WGANGPTrainer:
         """Moves the enclosed launches onto a non-blocking stream of the trainer when the caller sits on
         the NULL stream: the critic's CU-masked second stream is a blocking stream and would otherwise
         synchronise implicitly with every launch there.  The caller's stream waits for the work on exit."""
-        cur = torch.cuda.current_stream()
+        cur = ops.cur_stream()
         if not (self.D.overlap and cur.cuda_stream == 0):
             yield
             return
@@ -211,7 +211,7 @@ class WGANGPTrainer:
         if pre is not None and pre["labels"] is labels and (z is None or z is pre["z_in"]):
             self._join_generator()
             zg, lg, fake = pre["z"], pre["labels_gen"], self._fake_buf(self._fake_cur, B)
-            torch.cuda.current_stream().wait_event(pre["done"])
+            ops.cur_stream().wait_event(pre["done"])
             if alpha is None:
                 alpha = pre.get("alpha")
                 # the descriptors were built with or without dropout-mask rows: reuse them only if that
@@ -222,7 +222,7 @@ class WGANGPTrainer:
                 mask = pre["mask"]
         else:
             if pre is not None:
-                torch.cuda.current_stream().wait_event(pre["done"])     # keep the generator's buffer updates ordered
+                ops.cur_stream().wait_event(pre["done"])     # keep the generator's buffer updates ordered
             zg, lg = self._gen_inputs(z, labels, B)      # what the generator takes (the global batch's with several ranks)
             # this batch's own draws and sequence descriptors BEFORE the generator forward: after a generator
             # update that forward waits (just before its last layer) for the output layer's update on the side
@@ -256,7 +256,7 @@ class WGANGPTrainer:
                 nxt["z"], nxt["labels_gen"] = self._gen_inputs(nxt["z_in"], nxt["labels"], B)
                 self.G.forward(nxt["z"], nxt["labels_gen"], next_batch.get("U"), self.tau, self.hard, training=True,
                                save=False, out=other, heavy_after=heavy_after, workgroups=self.D.cu_masked)
-                nxt["done"].record()
+                ops.record(nxt["done"])
 
             def idle():
                 # the next step's own draws, made while this stream waits for the second-order sweeps
@@ -280,7 +280,7 @@ class WGANGPTrainer:
             def prefetch(heavy_after=None):
                 gp["fake"] = self.G.forward(zg, lg, gp["U"], self.tau, self.hard, training=True, save=True,
                                             heavy_after=heavy_after, workgroups=self.D.cu_masked)
-                gp["done"].record()
+                ops.record(gp["done"])
 
             def idle():
                 if gen_next.get("mask") is None and self.drop_rate > 0.0:
@@ -335,13 +335,13 @@ class WGANGPTrainer:
             z, lg = self._gen_inputs(z, labels, labels.shape[0])
         wsum = self.last["wsum"] if wsum is None else wsum
         if self._prefetched is not None:          # a prefetched forward nobody consumed: stay ordered behind it
-            torch.cuda.current_stream().wait_event(self._prefetched["done"])
+            ops.cur_stream().wait_event(self._prefetched["done"])
             self._prefetched = None
         B = labels.shape[0]
         n_global = B * self.comm.world
         gp, self._gen_prefetched = self._gen_prefetched, None
         if gp is not None:
-            torch.cuda.current_stream().wait_event(gp["done"])
+            ops.cur_stream().wait_event(gp["done"])
         if gp is not None and gp["z"] is z and gp["labels"] is labels and gp["U"] is U and "fake" in gp:
             fake = gp["fake"]                     # forward (and its saved activations) made beside the critic step
             if mask is None:
@@ -400,12 +400,12 @@ class WGANGPTrainer:
 
             def last_layer(dl2, a3, gather=False):
                 ready = torch.cuda.Event()
-                ready.record()
+                ops.record(ready)
                 keep.extend((dl2, a3))        # allocated on this stream, read on the other: alive until the join
                 with ops.on_stream(stream_s):
                     stream_s.wait_event(ready)
                     last_layer_update(dl2, a3, self.D.cu_masked, gather)
-                    done.record()
+                    ops.record(done)
 
             self.G.backward(dfake, last_layer=last_layer)
             self._adam(self.G, self.mG, self.vG, self.tG, 0, lo, reduce=small_reduce)
@@ -428,7 +428,7 @@ class WGANGPTrainer:
         (waited: the stream already waited for it, only the bookkeeping is left)."""
         if self._g_pending is not None:
             if not waited:
-                torch.cuda.current_stream().wait_event(self._g_pending[0])
+                ops.cur_stream().wait_event(self._g_pending[0])
             self._g_pending = None
             self.G.last_layer_ready = None
 

@@ -76,7 +76,7 @@ class _Fan:
     def join(self) -> None:
         """The current stream waits for everything queued on the two streams so far; what hold() kept is
         released behind that wait (a later allocation on the current stream is ordered after the readers)."""
-        cur = torch.cuda.current_stream()
+        cur = ops.cur_stream()
         for stream, ev in zip((self.b, self.c), self.join_ev):
             ev.record(stream)
             cur.wait_event(ev)
@@ -190,7 +190,7 @@ class _LstmStack:
             call("s2g_lstm64_stack_bwd", ctypes.byref(st), ptr(lengths), B, T, stream_ptr())
             if fan is not None:
                 fan.hold(*fused, *bparts, dh)
-                fan.fork_ev[1].record()
+                ops.record(fan.fork_ev[1])
                 for l, stream, sc in ((1, fan.b, fan.scratch_b), (0, fan.c, fan.scratch_c)):
                     with ops.on_stream(stream):
                         stream.wait_event(fan.fork_ev[1])
@@ -335,7 +335,7 @@ class ClipCriticEngine:
             ops.colsum(dpre, rows, HID, HID, g["attention.attn.bias"], sc_, accumulate=accumulate)
 
         if fan is not None and self.layers == 2:
-            fan.fork_ev[0].record()
+            ops.record(fan.fork_ev[0])
             with ops.on_stream(fan.b):
                 fan.b.wait_event(fan.fork_ev[0])
                 head_grads(fan.scratch_b)
@@ -431,22 +431,22 @@ class ClipCriticEngine:
                               [torch.cuda.Event() for _ in range(4)])
                 self._fan = _Fan(self._side[0], self._side[2], dev)
             side, grads2, scratch2, (e_in, e_fwd, e_loss, e_bwd) = self._side
-            cur = torch.cuda.current_stream()
-            e_in.record()
+            cur = ops.cur_stream()
+            ops.record(e_in)
             with ops.on_stream(side):
                 side.wait_event(e_in)
                 if make_fake is not None:
                     fake = make_fake()
                 _, s_fake = self.forward(fake, labels, None, fake.shape[1], masks_fake, dval[B:])
-                e_fwd.record()
+                ops.record(e_fwd)
             _, s_real = self.forward(real, labels, lengths, Tp, masks_real, dval[:B])
             cur.wait_event(e_fwd)
             call("s2g_wasserstein_loss", ptr(dval), B, ptr(dD), ptr(loss), stream_ptr())
-            e_loss.record()
+            ops.record(e_loss)
             with ops.on_stream(side):
                 side.wait_event(e_loss)
                 self.backward(s_fake, dD[B:], accumulate=False, grads=grads2, scratch=scratch2)
-                e_bwd.record()
+                ops.record(e_bwd)
             # the real pass's weight-gradient products follow the (short) fake pass on the second stream and on a third
             self.backward(s_real, dD[:B], accumulate=False, fan=self._fan)
             cur.wait_event(e_bwd)
