@@ -2,7 +2,9 @@
 takes a contiguous shard of the batch, normalises its loss by the GLOBAL batch size and the GLOBAL
 class-weight sum and SUM-all-reduces gradients; the generator's BatchNorm layers run replicated on the
 global batch (every rank knows all inputs), their backward on the all-gathered upstream gradient; the
-result must equal the single-process step on the whole batch (oracle arithmetic, float64)."""
+result must equal the single-process step on the whole batch (oracle arithmetic, float64).  The output
+Linear's gradient is formed from gathered FACTORS (rows of d(pre-activation), in column pieces started back to
+back) and the global input rows, not by summing the ranks' products."""
 import os
 import socket
 
@@ -88,6 +90,22 @@ def _worker(rank, port, ret):
     y_rep, dx_rep, dg_rep, db_rep = _replicated_bn(x, gamma, beta, dy[lo:hi], comm)
     assert comm.calls == 4          # world-size gather at set-up aside: wsum, gradient bucket, loss, d(y) gather
 
+    # output Linear: dW = dl2^T a3 over the GLOBAL batch from the gathered rows of dl2 (three column pieces,
+    # all started before the first is waited for) and a3 of the global batch, which every rank holds
+    NV = 11
+    a3 = torch.randn((B, 5), generator=common.gen(96), dtype=dt)
+    dl2 = torch.randn((B, NV), generator=common.gen(97), dtype=dt)
+    cuts = [(0, 4), (4, 8), (8, NV)]
+    started = [comm.allgather_rows_start(dl2[lo:hi, c0:c1]) for c0, c1 in cuts]
+    dW_fac = torch.empty(NV, 5, dtype=dt)
+    for (c0, c1), (rows, wait) in zip(cuts, started):
+        wait()
+        assert rows.shape == (B, c1 - c0)
+        dW_fac[c0:c1] = rows.t() @ a3
+    assert comm.calls == 7
+    dW_sum = dl2[lo:hi].t() @ a3[lo:hi]         # what an all-reduce of the ranks' products would deliver
+    comm.allreduce(dW_sum)
+
     if rank == 0:
         p1 = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
         full, _ = O.critic_loss(p1, real, lengths, fake, labels, alpha, 10.0)
@@ -100,6 +118,7 @@ def _worker(rank, port, ret):
         dx_ref, dg_ref, db_ref = torch.autograd.grad(y_ref, [xr, gr, br], dy)
         ret["grad_err"] = float((flat - ref).norm() / ref.norm())
         ret["loss_err"] = abs(float(lt[0]) - float(full))
+        ret["fac_err"] = max(float((dW_fac - dl2.t() @ a3).abs().max()), float((dW_fac - dW_sum).abs().max()))
         ret["bn_err"] = max(float((y_rep - y_ref.detach()).abs().max()), float((dx_rep - dx_ref).abs().max()),
                             float((dg_rep - dg_ref).abs().max()), float((db_rep - db_ref).abs().max()))
     comm.barrier()
@@ -114,3 +133,4 @@ def test_two_rank_step_equals_single_rank():
         assert ret["grad_err"] < 1e-10, dict(ret)
         assert ret["loss_err"] < 1e-10, dict(ret)
         assert ret["bn_err"] < 1e-10, dict(ret)
+        assert ret["fac_err"] < 1e-12, dict(ret)
