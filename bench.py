@@ -250,11 +250,15 @@ def bench_graph(steps, warmup, cpu_seconds=10.0):
 
 
 def main():
+    global GEN_SEQ_LEN
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--lengths", default="fixed", choices=["fixed", "adfa"])
+    ap.add_argument("--gen-seq-len", type=int, default=GEN_SEQ_LEN,
+                    help="the generator's seq_len: 512 = the headline shape; 120 = the reference's hard-coded default "
+                         "(wgan_gp.py:145), i.e. fakes shorter than the real sequences")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-wgan", action="store_true", help="skip the train_wgan() path measurement (profiling runs)")
     ap.add_argument("--drop-rate", type=float, default=0.3)
@@ -269,6 +273,7 @@ def main():
                          "(default, the headline) or the drop-in train_wgan() loop of wgan_gp.py on a CPU loader; "
                          "the other one is reported beside it on one GPU")
     a = ap.parse_args()
+    GEN_SEQ_LEN = a.gen_seq_len
 
     if a.variant == "attention":
         if not torch.cuda.is_available():
@@ -468,7 +473,7 @@ def main():
                                                      "weight-gradient products, f32 elsewhere",
             "data": "synthetic",
             "config": {"workload": "full WGAN-GP step = 5 critic updates (real+fake+gradient penalty) + 1 generator "
-                                   "update; V=175, L=512, B=64 per GPU, generator seq_len 512, tau 0.5, lambda_gp 10, "
+                                   f"update; V=175, L=512, B=64 per GPU, generator seq_len {GEN_SEQ_LEN}, tau 0.5, lambda_gp 10, "
                                    f"critic dropout {a.drop_rate}, lengths {a.lengths}",
                        "global_batch": B_PER_GPU * world, "seq_len": L, "parallelism": f"dp{world}"},
             "ms_per_critic_iteration_est": ms_per_step / (N_CRITIC + 0.3),

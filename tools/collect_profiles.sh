@@ -1,5 +1,5 @@
 set -e
-TAG=${1:-r03_b}
+TAG=${1:-r03_e}
 R=/root/repo; O=$R/gpurun_out/final; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 timeout -k 10 600 python -u -m pytest $R/tests -m gpu -x -q --timeout 120 --timeout-method thread -p no:cacheprovider > $O/gputests.log 2>&1
@@ -16,4 +16,6 @@ timeout -k 10 200 python bench.py --variant wgan_clip > $O/bench_wgan_clip.json 
 timeout -k 10 200 python bench.py --variant attention > $O/bench_attention.json 2>> $O/bench.err
 timeout -k 10 200 python bench.py --variant graph > $O/bench_graph.json 2>> $O/bench.err
 timeout -k 10 200 python bench.py --dtype bf16 --no-cpu-baseline --no-train-wgan > $O/bench_bf16.json 2>> $O/bench.err
+timeout -k 10 200 python bench.py --lengths adfa --no-cpu-baseline --no-train-wgan > $O/bench_adfa.json 2>> $O/bench.err
+timeout -k 10 200 python bench.py --lengths adfa --gen-seq-len 120 --no-cpu-baseline --no-train-wgan > $O/bench_adfa_gen120.json 2>> $O/bench.err
 echo ALLDONE
