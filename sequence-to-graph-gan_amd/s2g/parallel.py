@@ -45,9 +45,13 @@ class DistComm:
         if self.split:
             self.calls += 1
             if t.is_cuda and dist.get_backend(self.group) == "gloo":
-                # rehearsal on one GPU: gloo stages device tensors through the host and its own wait for a
-                # busy stream can hang with several processes on one card; drain the GPU first
-                torch.cuda.synchronize()
+                # rehearsal of several ranks on one GPU: gloo's own staging of device tensors (its copies and
+                # stream waits) stalls now and then with several processes on one card, also on a drained GPU,
+                # so the tensor crosses the host here and gloo only ever sees host memory
+                host = t.cpu()              # (synchronises with the current stream)
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                t.copy_(host)
+                return
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     def allgather_rows(self, t: torch.Tensor) -> torch.Tensor:
@@ -67,9 +71,13 @@ class DistComm:
         self.calls += 1
         out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         if dist.get_backend(self.group) == "gloo":
-            if t.is_cuda:
-                torch.cuda.synchronize()
-            dist.all_gather(list(out.chunk(self.world, 0)), t, group=self.group)
+            if t.is_cuda:                   # through the host, as in allreduce
+                host = t.cpu()
+                parts = [torch.empty_like(host) for _ in range(self.world)]
+                dist.all_gather(parts, host, group=self.group)
+                out.copy_(torch.cat(parts, 0))
+            else:
+                dist.all_gather(list(out.chunk(self.world, 0)), t, group=self.group)
             return out, (lambda: None)
         work = dist.all_gather_into_tensor(out, t, group=self.group, async_op=True)
         return out, (lambda: (work.wait(), None)[1])

@@ -22,6 +22,10 @@ DEV = "cuda:0" if BACKEND == "gloo" else "cuda:%d" % int(os.environ.get("LOCAL_R
 
 
 def main():
+    # a rank that is still alive after this many seconds prints every thread's stack and exits: the parent then
+    # fails with the stacks in its message instead of sitting out its own time limit
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ.get("S2G_DP_WATCHDOG", "100")), exit=True)
     from s2g.parallel import global_wsum, init_from_env, shard
     from s2g.trainer import WGANGPTrainer
     comm, rank, _, world = init_from_env(BACKEND, force_split=os.environ.get("S2G_DP_FORCE_SPLIT") == "1")

@@ -39,8 +39,8 @@ def _finish(procs, limit):
             for q in procs:
                 q.kill()
             pytest.fail("data-parallel worker did not finish:\n" + "\n".join(logs))
-    for p, log in zip(procs, logs):
-        assert p.returncode == 0, log
+    for p in procs:
+        assert p.returncode == 0, "\n---- next rank ----\n".join(logs)      # every rank's output: a stall needs both stacks
     return logs
 
 
